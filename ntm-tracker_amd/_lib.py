@@ -1,0 +1,77 @@
+"""ctypes binding to libntmtrack_hip.so (the C ABI declared in include/ntmtrack.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntmtrack_hip.so")
+
+_lib = None
+
+
+class NtkError(RuntimeError):
+    pass
+
+
+def _sig(lib):
+    c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    P = c_void_p
+    sigs = {
+        "ntk_version": (c_int, []),
+        "ntk_last_error": (ctypes.c_char_p, []),
+        "ntk_vgg_packed_k": (c_int, [c_int]),
+        "ntk_vgg_pack_weights": (c_int, [P, P, c_int, c_int, P]),
+        "ntk_vgg_conv3x3_relu_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+        "ntk_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+        "ntk_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+        "ntk_gemm_tn_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return sigs
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NtkError(
+                "libntmtrack_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C ntm-tracker_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        l._ntk_sigs = _sig(l)
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(lib()._ntk_sigs.keys())
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ntk_last_error()
+        raise NtkError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NtkError("expected a device tensor; the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise NtkError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

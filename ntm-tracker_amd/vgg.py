@@ -1,0 +1,98 @@
+"""VGG-16 conv1_1 .. conv4_3 feature extractor on the HIP MFMA conv kernel.
+
+Replaces the frozen-GraphDef import of the reference
+(direct_offset_output.py:417-422; layer spec vgg.py:155-161): ten
+[conv3x3 SAME + bias + ReLU] layers with 2x2/2 max-pools after conv1_2,
+conv2_2 and conv3_3 (fused into the producing conv's epilogue), NHWC fp32,
+TF HWIO weights.  The extractor is frozen (constants in the reference), so it
+is inference-only.
+"""
+import torch
+
+from . import _lib
+
+# (name, Cin, Cout, pool_after) -- vgg.py:155-160
+VGG_LAYERS = [
+    ("conv1_1", 3, 64, False), ("conv1_2", 64, 64, True),
+    ("conv2_1", 64, 128, False), ("conv2_2", 128, 128, True),
+    ("conv3_1", 128, 256, False), ("conv3_2", 256, 256, False), ("conv3_3", 256, 256, True),
+    ("conv4_1", 256, 512, False), ("conv4_2", 512, 512, False), ("conv4_3", 512, 512, False),
+]
+
+# algorithmic MACs per 224x224 frame: sum H*W*9*Cin*Cout
+def conv_flops_per_frame(h=224, w=224):
+    total = 0
+    for _name, cin, cout, pool in VGG_LAYERS:
+        total += 2 * h * w * 9 * cin * cout
+        if pool:
+            h //= 2
+            w //= 2
+    return total
+
+
+def conv3x3_relu(x, w_packed, bias, cin, cout, fuse_pool=False, out=None):
+    """x [F,H,W,Cin] fp32 NHWC device tensor -> relu(conv3x3_same(x)+b), optionally 2x2 max-pooled."""
+    F, H, W, C = x.shape
+    if C != cin:
+        raise _lib.NtkError("conv3x3_relu: input has %d channels, layer expects %d" % (C, cin))
+    oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
+    if out is None:
+        out = torch.empty((F, oh, ow, cout), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.ntk_vgg_conv3x3_relu_f32(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out),
+                                          F, H, W, cin, cout, 1 if fuse_pool else 0, _lib.stream()),
+               "ntk_vgg_conv3x3_relu_f32")
+    return out
+
+
+def pack_weights(w_hwio):
+    """[3,3,Cin,Cout] (TF HWIO) device tensor -> kernel layout [Cout][Kp]."""
+    kh, kw, cin, cout = w_hwio.shape
+    assert kh == 3 and kw == 3
+    L = _lib.lib()
+    kp = L.ntk_vgg_packed_k(cin)
+    wp = torch.empty((cout, kp), device=w_hwio.device, dtype=torch.float32)
+    _lib.check(L.ntk_vgg_pack_weights(_lib.ptr(w_hwio.contiguous()), _lib.ptr(wp), cin, cout, _lib.stream()),
+               "ntk_vgg_pack_weights")
+    return wp
+
+
+class VGG16Conv43(object):
+    """Frozen VGG-16 trunk up to conv4_3/Relu.
+
+    weights: {layer_name: (w_hwio [3,3,Cin,Cout], b [Cout])} as numpy arrays or tensors.
+    """
+
+    def __init__(self, weights, device="cuda", chunk_frames=64):
+        self.device = torch.device(device)
+        self.chunk_frames = int(chunk_frames)
+        self.packed = {}
+        for name, cin, cout, _pool in VGG_LAYERS:
+            w, b = weights[name]
+            w = torch.as_tensor(w, dtype=torch.float32).to(self.device)
+            b = torch.as_tensor(b, dtype=torch.float32).to(self.device).contiguous()
+            if tuple(w.shape) != (3, 3, cin, cout):
+                raise _lib.NtkError("%s: weight shape %s != (3,3,%d,%d)" % (name, tuple(w.shape), cin, cout))
+            self.packed[name] = (pack_weights(w), b)
+
+    def forward_chunk(self, frames, upto="conv4_3", out=None):
+        x = frames
+        for name, cin, cout, pool in VGG_LAYERS:
+            wp, b = self.packed[name]
+            last = (name == upto)
+            x = conv3x3_relu(x, wp, b, cin, cout, fuse_pool=(pool and not last), out=out if last else None)
+            if last:
+                break
+        return x
+
+    def __call__(self, frames, out=None):
+        """frames [F,224,224,3] mean-subtracted fp32 NHWC -> [F,28,28,512]."""
+        if frames.dim() != 4 or frames.shape[3] != 3:
+            raise _lib.NtkError("frames must be [F,H,W,3] NHWC")
+        F, H, W, _ = frames.shape
+        if out is None:
+            out = torch.empty((F, H // 8, W // 8, 512), device=frames.device, dtype=torch.float32)
+        for f0 in range(0, F, self.chunk_frames):
+            f1 = min(F, f0 + self.chunk_frames)
+            self.forward_chunk(frames[f0:f1], out=out[f0:f1])
+        return out

@@ -1,0 +1,66 @@
+"""GPU parity: HIP MFMA conv / VGG trunk vs the numpy oracle (oracle/ntm_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ntm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.mark.parametrize("F,H,W,cin,cout,pool", [
+    (2, 8, 12, 3, 64, False),      # conv1_1 path (tiny Cin, scalar gather loader)
+    (1, 16, 16, 3, 64, True),
+    (3, 8, 8, 64, 64, True),       # BN=64 tile, fused pool
+    (2, 12, 8, 64, 128, False),    # BN=128 tile
+    (1, 28, 28, 256, 512, False),  # conv4_1 shape, one frame (ragged last row-tile: 784 = 6*128+16)
+    (3, 4, 4, 32, 64, False),      # smallest legal image
+    (2, 8, 8, 128, 256, True),
+])
+def test_conv3x3_relu_matches_oracle(cuda, F, H, W, cin, cout, pool):
+    from ntmtrack import vgg
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((F, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    ref = O.conv3x3_same_relu(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    if pool:
+        ref = O.maxpool2x2(ref)
+    wp = vgg.pack_weights(torch.from_numpy(w).to(cuda))
+    out = vgg.conv3x3_relu(torch.from_numpy(x).to(cuda), wp, torch.from_numpy(b).to(cuda), cin, cout, fuse_pool=pool)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    # fp32 MFMA = k-ordered fmaf chain: error ~1e-7 * sum|a*b|; tolerance 1e-5 relative to max
+    assert _rel(got, ref) < 1e-5
+
+
+def test_conv_rejects_bad_shapes(cuda):
+    from ntmtrack import vgg, _lib
+    x = torch.zeros((1, 6, 8, 32), device=cuda)
+    wp = torch.zeros((64, 288), device=cuda)
+    b = torch.zeros(64, device=cuda)
+    with pytest.raises(_lib.NtkError):
+        vgg.conv3x3_relu(x, wp, b, 32, 64)       # H not a multiple of 4
+    x = torch.zeros((1, 8, 8, 48), device=cuda)
+    with pytest.raises(_lib.NtkError):
+        vgg.conv3x3_relu(x, wp, b, 48, 64)       # Cin neither 3 nor multiple of 32
+
+
+def test_vgg_trunk_matches_oracle_small(cuda):
+    """Full conv1_1..conv4_3 stack on 2 frames of 32x32 (oracle finishes in seconds)."""
+    from ntmtrack import vgg
+    rng = np.random.default_rng(42)
+    ws = O.init_vgg_weights(rng)
+    frames = (rng.uniform(0, 255, size=(2, 32, 32, 3)).astype(np.float32) - O.VGG_MEAN)
+    ref = O.vgg16_conv43(frames.astype(np.float64), {k: (w.astype(np.float64), b.astype(np.float64)) for k, (w, b) in ws.items()})
+    net = vgg.VGG16Conv43(ws, device=cuda)
+    out = net(torch.from_numpy(frames).to(cuda))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert got.shape == (2, 4, 4, 512)
+    assert _rel(got, ref) < 1e-4   # north_star tolerance (1e-4 fp32) through 10 layers
