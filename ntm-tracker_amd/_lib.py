@@ -30,6 +30,15 @@ def _sig(lib):
         "ntk_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
         "ntk_gemm_tn_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+        "ntk_ntm_padded_dims": (c_int, [c_int] * 7 + [ctypes.POINTER(c_int)] * 5),
+        "ntk_ntm_seq_fwd": (c_int, [c_int] * 10 + [P] * 23 + [P]),
+        "ntk_gather_serialize": (c_int, [P, P, P] + [c_int] * 9 + [P]),
+        "ntk_offset_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+        "ntk_ntm_init_state": (c_int, [P, P, c_int, c_int, c_int, P]),
+        "ntk_ntm_init_state_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+        "ntk_global_norm_workspace_bytes": (c_size_t, [c_size_t]),
+        "ntk_global_norm": (c_int, [P, c_size_t, P, P, P]),
+        "ntk_rmsprop_clip_step": (c_int, [P, P, P, P, c_size_t] + [ctypes.c_float] * 5 + [P, P]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: fail loudly

@@ -1,0 +1,223 @@
+// Tracking head around the NTM cell, initial state, and the optimiser:
+//   * 64-point gather from conv4_3 + input serialiser   (direct_offset_output.py:392-399, :439-500)
+//   * output gather + tanh + l2 loss, and its gradient   (:581-606)
+//   * trainable initial state tanh/sigmoid + its gradient (ntm_cell.py:284-315)
+//   * clip_by_global_norm + TF RMSProp                    (direct_offset_output.py:620-626)
+// All HBM-bound elementwise / gather work: coalesced 16-byte accesses, no LDS.
+#include "common.h"
+
+namespace {
+
+// one 128-thread workgroup per serialised row (b, t, i), i in [0, NF]; row i == NF is the delimiter
+__global__ void gather_serialize_kernel(const float* __restrict__ fmap, const float* __restrict__ gts0,
+                                        float* __restrict__ X, int T, int Hf, int Wf, int C, int ldx,
+                                        int g0, int gstep, int gn) {
+    const int NF = gn * gn;
+    const int row = blockIdx.x;               // (b*T + t)*(NF+1) + i
+    const int i = row % (NF + 1);
+    const int ft = row / (NF + 1);            // b*T + t
+    const int t = ft % T, b = ft / T;
+    float* xr = X + (size_t)row * ldx;
+    const int C4 = C >> 2;
+    if (i < NF) {
+        const int y = g0 + (i / gn) * gstep, x = g0 + (i % gn) * gstep;
+        const f32x4* src = reinterpret_cast<const f32x4*>(fmap + (((size_t)ft * Hf + y) * Wf + x) * C);
+        f32x4* dst = reinterpret_cast<f32x4*>(xr);
+        for (int c = threadIdx.x; c < C4; c += blockDim.x) dst[c] = src[c];
+    } else {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4* dst = reinterpret_cast<f32x4*>(xr);
+        for (int c = threadIdx.x; c < C4; c += blockDim.x) dst[c] = z;
+    }
+    for (int c = C + threadIdx.x; c < ldx; c += blockDim.x) {
+        float v = 0.f;
+        if (c == C) v = (i == NF) ? 1.f : 0.f;                                    // frame delimiter bit
+        else if (c == C + 1) v = (t == 0 && i < NF && gts0) ? gts0[(size_t)b * NF + i] : 0.f;  // target, frame 0 only
+        xr[c] = v;
+    }
+}
+
+// single workgroup: pred = tanh(logit at the delimiter step of frames 1..T-1), loss = 0.5*sum (pred-off)^2,
+// dlogits = (pred-off)*(1-pred^2) at those steps and 0 elsewhere
+__global__ __launch_bounds__(1024) void offset_loss_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ offsets,
+                                                            float* __restrict__ pred, float* __restrict__ loss,
+                                                            float* __restrict__ dlogits, int B, int T, int NF, int O) {
+    __shared__ float red[16];
+    const int S = T * (NF + 1);
+    const int tid = threadIdx.x;
+    if (dlogits) {
+        const size_t tot = (size_t)B * S * O;
+        for (size_t i = tid; i < tot; i += blockDim.x) dlogits[i] = 0.f;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    const int cnt = B * (T - 1) * O;
+    for (int i = tid; i < cnt; i += blockDim.x) {
+        const int o = i % O;
+        const int bt = i / O;
+        const int t = bt % (T - 1) + 1, b = bt / (T - 1);
+        const size_t li = ((size_t)b * S + (size_t)t * (NF + 1) + NF) * O + o;
+        const float p = tanhf(logits[li]);
+        const float dlt = p - offsets[((size_t)b * T + t) * O + o];
+        acc += dlt * dlt;
+        if (pred) pred[i] = p;
+        if (dlogits) dlogits[li] = dlt * (1.0f - p * p);
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        *loss = 0.5f * s;
+    }
+}
+
+// act: 0 = tanh, 1 = sigmoid.  out[b][i] = act(v[i])
+__global__ void init_state_kernel(const float* __restrict__ v, float* __restrict__ out, int n, int B, int act) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = v[i];
+    const float y = act ? 1.0f / (1.0f + expf(-x)) : tanhf(x);
+    for (int b = 0; b < B; ++b) out[(size_t)b * n + i] = y;
+}
+
+// dv[i] (+)= act'(v[i]) * sum_b dout[b][i]
+__global__ void init_state_bwd_kernel(const float* __restrict__ v, const float* __restrict__ dout,
+                                      float* __restrict__ dv, int n, int B, int act, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dout[(size_t)b * n + i];
+    const float x = v[i];
+    float dy;
+    if (act) { const float y = 1.0f / (1.0f + expf(-x)); dy = y * (1.0f - y); }
+    else { const float y = tanhf(x); dy = 1.0f - y * y; }
+    const float g = s * dy;
+    dv[i] = accumulate ? dv[i] + g : g;
+}
+
+constexpr int SUMSQ_BLOCK = 256;
+constexpr int SUMSQ_PER_BLOCK = 4096;
+
+__global__ void sumsq_partial_kernel(const float* __restrict__ g, float* __restrict__ partial, size_t n) {
+    __shared__ float red[SUMSQ_BLOCK / 64];
+    const size_t base = (size_t)blockIdx.x * SUMSQ_PER_BLOCK;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < SUMSQ_PER_BLOCK; i += SUMSQ_BLOCK) {
+        const size_t idx = base + i;
+        if (idx < n) { const float v = g[idx]; acc += v * v; }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < SUMSQ_BLOCK / 64; ++w) s += red[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ gnorm) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        *gnorm = sqrtf(s);
+    }
+}
+
+// tf.clip_by_global_norm then tf.train.RMSPropOptimizer (ms slot starts at ONE, eps inside the sqrt)
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms,
+                               float* __restrict__ mom, size_t n, float lr, float decay, float momentum,
+                               float eps, float clip, const float* __restrict__ gnorm) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float scale = 1.0f;
+    if (clip > 0.f) scale = clip / fmaxf(*gnorm, clip);
+    const float gi = g[i] * scale;
+    const float m2 = decay * ms[i] + (1.0f - decay) * gi * gi;
+    const float mo = momentum * mom[i] + lr * gi / sqrtf(m2 + eps);
+    ms[i] = m2;
+    mom[i] = mo;
+    p[i] -= mo;
+}
+
+}  // namespace
+
+extern "C" int ntk_gather_serialize(const float* fmap, const float* gts0, float* X, int B, int T,
+                                    int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
+                                    int grid_n, void* stream) {
+    NTK_REQUIRE(fmap && X, NTK_ERR_BAD_PTR, "ntk_gather_serialize: null pointer");
+    NTK_REQUIRE(ntk_aligned16(fmap) && ntk_aligned16(X), NTK_ERR_BAD_PTR, "ntk_gather_serialize: 16-byte alignment");
+    NTK_REQUIRE(B > 0 && T > 0 && C > 0 && (C % 4) == 0 && ldx >= C + 2 && (ldx % 4) == 0 && grid_n > 0 &&
+                    grid_start >= 0 && grid_step > 0 && grid_start + (grid_n - 1) * grid_step < Hf &&
+                    grid_start + (grid_n - 1) * grid_step < Wf,
+                NTK_ERR_BAD_SHAPE, "ntk_gather_serialize: B=%d T=%d C=%d ldx=%d grid=(%d,%d,%d) map=%dx%d", B, T, C,
+                ldx, grid_start, grid_step, grid_n, Hf, Wf);
+    const long rows = (long)B * T * (grid_n * grid_n + 1);
+    NTK_REQUIRE(rows < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_gather_serialize: too many rows");
+    gather_serialize_kernel<<<(unsigned)rows, 128, 0, (hipStream_t)stream>>>(fmap, gts0, X, T, Hf, Wf, C, ldx,
+                                                                            grid_start, grid_step, grid_n);
+    NTK_CHECK_LAUNCH("ntk_gather_serialize");
+    return NTK_OK;
+}
+
+extern "C" int ntk_offset_loss(const float* logits, const float* offsets, float* pred, float* loss,
+                               float* dlogits, int B, int T, int NF, int O, void* stream) {
+    NTK_REQUIRE(logits && offsets && loss, NTK_ERR_BAD_PTR, "ntk_offset_loss: null pointer");
+    NTK_REQUIRE(B > 0 && T >= 2 && NF > 0 && O > 0, NTK_ERR_BAD_SHAPE, "ntk_offset_loss: B=%d T=%d NF=%d O=%d (T >= 2)", B, T, NF, O);
+    offset_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, offsets, pred, loss, dlogits, B, T, NF, O);
+    NTK_CHECK_LAUNCH("ntk_offset_loss");
+    return NTK_OK;
+}
+
+extern "C" int ntk_ntm_init_state(const float* v, float* out, int n, int B, int act, void* stream) {
+    NTK_REQUIRE(v && out, NTK_ERR_BAD_PTR, "ntk_ntm_init_state: null pointer");
+    NTK_REQUIRE(n > 0 && B > 0 && (act == 0 || act == 1), NTK_ERR_BAD_SHAPE, "ntk_ntm_init_state: n=%d B=%d act=%d", n, B, act);
+    init_state_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(v, out, n, B, act);
+    NTK_CHECK_LAUNCH("ntk_ntm_init_state");
+    return NTK_OK;
+}
+
+extern "C" int ntk_ntm_init_state_bwd(const float* v, const float* dout, float* dv, int n, int B, int act,
+                                      int accumulate, void* stream) {
+    NTK_REQUIRE(v && dout && dv, NTK_ERR_BAD_PTR, "ntk_ntm_init_state_bwd: null pointer");
+    NTK_REQUIRE(n > 0 && B > 0 && (act == 0 || act == 1), NTK_ERR_BAD_SHAPE, "ntk_ntm_init_state_bwd: n=%d B=%d act=%d", n, B, act);
+    init_state_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(v, dout, dv, n, B, act, accumulate);
+    NTK_CHECK_LAUNCH("ntk_ntm_init_state_bwd");
+    return NTK_OK;
+}
+
+extern "C" size_t ntk_global_norm_workspace_bytes(size_t n) {
+    return ((n + SUMSQ_PER_BLOCK - 1) / SUMSQ_PER_BLOCK) * sizeof(float);
+}
+
+extern "C" int ntk_global_norm(const float* grads, size_t n, float* workspace, float* gnorm, void* stream) {
+    NTK_REQUIRE(grads && workspace && gnorm, NTK_ERR_BAD_PTR, "ntk_global_norm: null pointer");
+    NTK_REQUIRE(n > 0, NTK_ERR_BAD_SHAPE, "ntk_global_norm: n=0");
+    const int nb = (int)((n + SUMSQ_PER_BLOCK - 1) / SUMSQ_PER_BLOCK);
+    sumsq_partial_kernel<<<nb, SUMSQ_BLOCK, 0, (hipStream_t)stream>>>(grads, workspace, n);
+    NTK_CHECK_LAUNCH("ntk_global_norm(partial)");
+    sumsq_final_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(workspace, nb, gnorm);
+    NTK_CHECK_LAUNCH("ntk_global_norm(final)");
+    return NTK_OK;
+}
+
+extern "C" int ntk_rmsprop_clip_step(float* params, const float* grads, float* ms, float* mom, size_t n,
+                                     float lr, float decay, float momentum, float eps, float clip_norm,
+                                     const float* gnorm, void* stream) {
+    NTK_REQUIRE(params && grads && ms && mom, NTK_ERR_BAD_PTR, "ntk_rmsprop_clip_step: null pointer");
+    NTK_REQUIRE(n > 0, NTK_ERR_BAD_SHAPE, "ntk_rmsprop_clip_step: n=0");
+    NTK_REQUIRE(clip_norm <= 0.f || gnorm, NTK_ERR_BAD_PTR, "ntk_rmsprop_clip_step: clip_norm > 0 needs gnorm");
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    rmsprop_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(params, grads, ms, mom, n, lr, decay, momentum, eps, clip_norm, gnorm);
+    NTK_CHECK_LAUNCH("ntk_rmsprop_clip_step");
+    return NTK_OK;
+}

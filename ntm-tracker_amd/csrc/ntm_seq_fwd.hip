@@ -1,0 +1,420 @@
+// NTM sequence forward: one persistent workgroup per sequence walks all S
+// steps of NTMCell.__call__ (ntm_cell.py:53-253) with the whole recurrent state
+// (memory N x Md, head weights H x N, reads, LSTM c/h) resident in LDS; only
+// the weights are streamed (from L2) and the per-step tensors the BPTT pass
+// needs are written once, coalesced, to HBM.  Replaces the tf.while_loop of
+// LoopNTMTracker (ntm_tracker_new.py:13-64), S sequential TF graph iterations.
+//
+// Per step (all phases separated by workgroup barriers):
+//   P1 gate partials      z=[read_prev;h_prev] (K) x Wr[K][4*hid]   (K-sliced over thread groups)
+//   P2 LSTM cell          BasicLSTMCell, gate order i,j,f,o, forget_bias 0 (ntm_cell.py:45-50)
+//                         + column sum-of-squares partials of M for quirk Q1
+//   P3 unpack partials    h' x Wa[hid][PP]                           (ntm_cell.py:124-126, :220)
+//   P4 control activations tanh/softplus/sigmoid/1+softplus           (:133,140,151,169,193,195)
+//   P5 key scaling, shift softmax, output softmax                     (ops.py:150-152, ntm_cell.py:161,221)
+//   P6 similarity (Q1: feature columns normalised over slots), beta, softmax over N, gate (:136-156)
+//   P7 circular shift with taps -(r+1)..r-1 (Q2), sharpen with +1e-3 (Q4)   (ops.py:204-213, ntm_cell.py:173-176)
+//   P8 erase/add write and read (reads see the pre-write memory unless write_first, Q6) (:202-215)
+#include "ntm_common.h"
+
+struct NtmFwdArgs {
+    NtmDims d;
+    // inputs
+    const float* xproj;    // [B,S,4*hid]  X * Wx (columns n' = unit*4+gate), no bias
+    const float* Wr;       // [ldz][4*hid]
+    const float* Wa;       // [ldh][PP]
+    const float* M0;       // [B,N,Md]
+    const float* w0;       // [B,H,N]
+    const float* read0;    // [B,R,Md]
+    const float* cs0;      // [B,2*hid]  (c then h)
+    // outputs
+    float* logits;         // [B,S,O]
+    float* outputs;        // [B,S,O] softmax(logits) or null
+    float* M_out;          // [B,N,Md]
+    float* w_out;          // [B,H,N]
+    float* read_out;       // [B,R,Md]
+    float* cs_out;         // [B,2*hid]
+    // per-step records (all nullable): what LoopNTMTracker writes to its TensorArrays plus the BPTT stash
+    float* st_z;           // [B,S,ldz]   step input [read_prev;h_prev;1;0..]
+    float* st_gates;       // [B,S,4*hid] activated gates (i,j,f,o per unit)
+    float* st_c;           // [B,S,hid]
+    float* st_h;           // [B,S,ldh]   [h';1;0..]
+    float* st_u;           // [B,S,PP]    activated controls, raw shift logits, raw output logits
+    float* st_wc;          // [B,S,H,N]   content-focused weights
+    float* st_wv;          // [B,S,H,N]   shifted weights (before sharpening)
+    float* st_w;           // [B,S,H,N]
+    float* st_M;           // [B,S,N,Md]
+    float* st_read;        // [B,S,R,Md]
+};
+
+static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
+    const int MP = d.Md | 1;
+    const int nsl = ntm_imax(1, T / d.hid);
+    const int ncg = d.PP / 4;
+    const int nslB = ntm_imin(ntm_imax(1, T / ncg), d.hid);
+    const int RM = d.R * d.Md;
+    const int nslR = ntm_imin(ntm_imax(1, T / RM), d.N);
+    const int nslC = ntm_imax(1, (T - d.hid) / d.Md);
+    int o = 0;
+    L.part = o; o += ntm_align4(ntm_imax(ntm_imax(nsl * 4 * d.hid, nslB * d.PP), nslR * RM));
+    L.M = o; o += ntm_align4(d.N * MP);
+    L.W = o; o += ntm_align4(d.H * d.N);
+    L.Wg = o; o += ntm_align4(d.H * d.N);
+    L.Z = o; o += ntm_align4(d.K);
+    L.C = o; o += ntm_align4(d.hid);
+    L.U = o; o += ntm_align4(d.PP);
+    L.Ks = o; o += ntm_align4(d.H * d.Md);
+    L.Cn = o; o += ntm_align4(d.Md);
+    L.CnPart = o; o += ntm_align4(nslC * d.Md);
+    L.Sw = o; o += ntm_align4(d.H * d.SS);
+    L.Red = o; o += ntm_align4(2 * d.H * (d.N / 64));
+    L.total = o;
+}
+
+__global__ __launch_bounds__(1024) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NtmDims& d = a.d;
+    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63;
+    const int N = d.N, Md = d.Md, MP = d.Md | 1, R = d.R, Wh = d.Wh, H = d.H, hid = d.hid;
+    const int S = d.S, K = d.K, PP = d.PP, RM = R * Md, SS = d.SS, NW = N >> 6;
+
+    float* sPart = smem + L.part;
+    float* sM = smem + L.M;
+    float* sW = smem + L.W;
+    float* sWg = smem + L.Wg;
+    float* sZ = smem + L.Z;
+    float* sC = smem + L.C;
+    float* sU = smem + L.U;
+    float* sKs = smem + L.Ks;
+    float* sCn = smem + L.Cn;
+    float* sCnPart = smem + L.CnPart;
+    float* sSw = smem + L.Sw;
+    float* sRedMax = smem + L.Red;
+    float* sRedSum = sRedMax + H * NW;
+
+    // work decomposition (uniform per kernel)
+    const int nsl = max(1, T / hid);                 // K-slices of the gate product
+    const int kper = (K + nsl - 1) / nsl;
+    const int ncg = PP >> 2;                          // float4 column groups of the unpack product
+    const int nslB = min(max(1, T / ncg), hid);
+    const int kperB = (hid + nslB - 1) / nslB;
+    const int nslR = min(max(1, T / RM), N);          // N-slices of the read product
+    const int nperR = (N + nslR - 1) / nslR;
+    const int nslC = max(1, (T - hid) / Md);          // N-slices of the column sum of squares
+    const int hpp = T / N;                            // heads handled per pass of P6/P7
+
+    // ---- load the initial state
+    for (int i = tid; i < N * Md; i += T) sM[(i / Md) * MP + (i % Md)] = a.M0[(size_t)b * N * Md + i];
+    for (int i = tid; i < H * N; i += T) sW[i] = a.w0[(size_t)b * H * N + i];
+    for (int i = tid; i < RM; i += T) sZ[i] = a.read0[(size_t)b * RM + i];
+    for (int i = tid; i < hid; i += T) {
+        sC[i] = a.cs0[(size_t)b * 2 * hid + i];
+        sZ[RM + i] = a.cs0[(size_t)b * 2 * hid + hid + i];
+    }
+    __syncthreads();
+
+    const f32x4* Wr4 = reinterpret_cast<const f32x4*>(a.Wr);
+    const f32x4* Wa4 = reinterpret_cast<const f32x4*>(a.Wa);
+    f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
+
+    for (int t = 0; t < S; ++t) {
+        const size_t bt = (size_t)b * S + t;
+        // ------------------------------------------------------------ P1
+        f32x4 xg = {0.f, 0.f, 0.f, 0.f};
+        if (tid < hid) {   // prefetch this step's input projection + LSTM bias (row K of Wr)
+            xg = reinterpret_cast<const f32x4*>(a.xproj)[bt * hid + tid];
+            const f32x4 bb = Wr4[(size_t)K * hid + tid];
+            xg += bb;
+        }
+        if (a.st_z) {
+            for (int i = tid; i < d.ldz; i += T)
+                a.st_z[bt * d.ldz + i] = (i < K) ? sZ[i] : (i == K ? 1.f : 0.f);
+        }
+        if (tid < nsl * hid) {
+            const int j = tid % hid, ks = tid / hid;
+            const int k0 = ks * kper, k1 = min(K, k0 + kper);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const f32x4* wp = Wr4 + (size_t)k0 * hid + j;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k, wp += hid) {
+                const float zk = sZ[k];
+                const f32x4 w = *wp;
+                acc += zk * w;
+            }
+            sPart4[ks * hid + j] = acc;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ P2
+        if (tid < hid) {
+            f32x4 g = xg;
+            for (int ks = 0; ks < nsl; ++ks) g += sPart4[ks * hid + tid];
+            const float gi = ntm_sigmoid(g[0]);
+            const float gj = tanhf(g[1]);
+            const float gf = ntm_sigmoid(g[2]);      // forget_bias = 0.0 (ntm_cell.py:47)
+            const float go = ntm_sigmoid(g[3]);
+            const float c2 = sC[tid] * gf + gi * gj;
+            const float h2 = tanhf(c2) * go;
+            sC[tid] = c2;
+            sZ[RM + tid] = h2;
+            if (a.st_gates) {
+                f32x4 ga = {gi, gj, gf, go};
+                reinterpret_cast<f32x4*>(a.st_gates)[bt * hid + tid] = ga;
+                a.st_c[bt * hid + tid] = c2;
+            }
+            if (a.st_h) a.st_h[bt * d.ldh + tid] = h2;
+        } else {
+            const int idx = tid - hid;
+            const int m = idx % Md, sl = idx / Md;
+            if (sl < nslC) {
+                float s = 0.f;
+                for (int n = sl; n < N; n += nslC) { const float v = sM[n * MP + m]; s += v * v; }
+                sCnPart[sl * Md + m] = s;
+            }
+            if (a.st_h && idx < d.ldh - hid) a.st_h[bt * d.ldh + hid + idx] = (idx == 0) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ P3
+        if (tid < nslB * ncg) {
+            const int cg = tid % ncg, ks = tid / ncg;
+            const int k0 = ks * kperB, k1 = min(hid, k0 + kperB);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const f32x4* wp = Wa4 + (size_t)k0 * ncg + cg;
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k, wp += ncg) {
+                const float hk = sZ[RM + k];
+                const f32x4 w = *wp;
+                acc += hk * w;
+            }
+            sPart4[ks * ncg + cg] = acc;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ P4
+        if (tid < PP) {
+            float v = a.Wa[(size_t)hid * PP + tid];
+            for (int ks = 0; ks < nslB; ++ks) v += sPart[ks * PP + tid];
+            float r = v;
+            if (tid < d.oB) r = tanhf(v);                          // k      :133
+            else if (tid < d.oG) r = ntm_softplus(v);              // beta   :140
+            else if (tid < d.oS) r = ntm_sigmoid(v);               // g      :151
+            else if (tid < d.oY) r = v;                            // shift logits (softmax in P5)
+            else if (tid < d.oE) r = ntm_softplus(v) + 1.0f;       // gamma  :169-170
+            else if (tid < d.oA) r = ntm_sigmoid(v);               // erase  :193
+            else if (tid < d.P) r = tanhf(v);                      // add    :195
+            sU[tid] = r;
+            if (a.st_u) a.st_u[bt * PP + tid] = r;
+            if (tid >= d.P && tid < d.P + d.O) a.logits[bt * d.O + (tid - d.P)] = v;
+        } else if (tid < PP + Md) {
+            const int m = tid - PP;
+            float s = 0.f;
+            for (int sl = 0; sl < nslC; ++sl) s += sCnPart[sl * Md + m];
+            sCn[m] = 1.0f / sqrtf(fmaxf(s, 1e-12f));             // tf.nn.l2_normalize over the slot axis (Q1)
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ P5
+        if (tid < H * Md) {
+            const int h = tid / Md, m = tid - h * Md;
+            float ss = 0.f;
+            for (int mm = 0; mm < Md; ++mm) { const float kv = sU[d.oK + h * Md + mm]; ss += kv * kv; }
+            sKs[tid] = sU[d.oK + tid] * (1.0f / sqrtf(fmaxf(ss, 1e-12f))) * sCn[m];
+        } else if (tid < H * Md + H) {
+            const int h = tid - H * Md;
+            float mx = -INFINITY;
+            for (int j = 0; j < SS; ++j) mx = fmaxf(mx, sU[d.oS + h * SS + j]);
+            float sum = 0.f;
+            for (int j = 0; j < SS; ++j) sum += expf(sU[d.oS + h * SS + j] - mx);
+            for (int j = 0; j < SS; ++j) sSw[h * SS + j] = expf(sU[d.oS + h * SS + j] - mx) / sum;
+        } else if (tid == H * Md + H && a.outputs) {
+            float mx = -INFINITY;
+            for (int j = 0; j < d.O; ++j) mx = fmaxf(mx, sU[d.P + j]);
+            float sum = 0.f;
+            for (int j = 0; j < d.O; ++j) sum += expf(sU[d.P + j] - mx);
+            for (int j = 0; j < d.O; ++j) a.outputs[bt * d.O + j] = expf(sU[d.P + j] - mx) / sum;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ P6: content addressing + gate
+        for (int h0 = 0; h0 < H; h0 += hpp) {
+            const int hl = tid / N, n = tid - hl * N, h = h0 + hl;
+            const bool act = (hl < hpp) && (h < H);
+            const int wi = n >> 6;
+            float v = -INFINITY;
+            if (act) {
+                float sim = 0.f;
+                for (int m = 0; m < Md; ++m) sim += sKs[h * Md + m] * sM[n * MP + m];
+                v = sim * sU[d.oB + h];
+            }
+            const float wmx = wave_max(v);
+            if (act && lane == 0) sRedMax[h * NW + wi] = wmx;
+            __syncthreads();
+            float e = 0.f;
+            if (act) {
+                float mx = sRedMax[h * NW];
+                for (int q = 1; q < NW; ++q) mx = fmaxf(mx, sRedMax[h * NW + q]);
+                e = expf(v - mx);
+            }
+            const float wsm = wave_sum(e);
+            if (act && lane == 0) sRedSum[h * NW + wi] = wsm;
+            __syncthreads();
+            if (act) {
+                float tot = 0.f;
+                for (int q = 0; q < NW; ++q) tot += sRedSum[h * NW + q];
+                const float wc = e / tot;
+                const float g = sU[d.oG + h];
+                const float wg = wc * g + sW[h * N + n] * (1.0f - g);
+                sWg[h * N + n] = wg;
+                if (a.st_wc) a.st_wc[(bt * H + h) * N + n] = wc;
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ P7: shift + sharpen
+        for (int h0 = 0; h0 < H; h0 += hpp) {
+            const int hl = tid / N, n = tid - hl * N, h = h0 + hl;
+            const bool act = (hl < hpp) && (h < H);
+            const int wi = n >> 6;
+            float pw = 0.f;
+            if (act) {
+                float wv = 0.f;
+                const int start = -((SS + 1) >> 1);              // Py2 floor of -SS/2 (Q2): 3 -> -2
+                for (int j = 0; j < SS; ++j) {
+                    int src = n + start + j;
+                    src = (src % N + N) % N;
+                    wv += sSw[h * SS + j] * sWg[h * N + src];
+                }
+                if (a.st_wv) a.st_wv[(bt * H + h) * N + n] = wv;
+                pw = powf(wv, sU[d.oY + h]);
+            }
+            const float wsm = wave_sum(pw);
+            if (act && lane == 0) sRedSum[h * NW + wi] = wsm;
+            __syncthreads();
+            if (act) {
+                float tot = 0.f;
+                for (int q = 0; q < NW; ++q) tot += sRedSum[h * NW + q];
+                const float w = pw / (tot + 1e-3f);
+                sW[h * N + n] = w;
+                if (a.st_w) a.st_w[(bt * H + h) * N + n] = w;
+            }
+            __syncthreads();
+        }
+        // ------------------------------------------------------------ P8: write + read
+        auto update_M = [&]() {
+            for (int idx = tid; idx < N * Md; idx += T) {
+                const int n = idx / Md, m = idx - n * Md;
+                float E = 1.f, A = 0.f;
+                for (int j = 0; j < Wh; ++j) {
+                    const float ww = sW[(R + j) * N + n];
+                    E *= (1.0f - ww * sU[d.oE + j * Md + m]);
+                    A += ww * sU[d.oA + j * Md + m];
+                }
+                const float nm = sM[n * MP + m] * E + A;
+                sM[n * MP + m] = nm;
+                if (a.st_M) a.st_M[bt * N * Md + idx] = nm;
+            }
+        };
+        if (d.write_first) { update_M(); __syncthreads(); }
+        if (tid < nslR * RM) {
+            const int o = tid % RM, sl = tid / RM;
+            const int i = o / Md, m = o - i * Md;
+            const int n0 = sl * nperR, n1 = min(N, n0 + nperR);
+            float s = 0.f;
+            for (int n = n0; n < n1; ++n) s += sW[i * N + n] * sM[n * MP + m];
+            sPart[sl * RM + o] = s;
+        }
+        __syncthreads();
+        if (!d.write_first) update_M();
+        if (tid < RM) {
+            float s = 0.f;
+            for (int sl = 0; sl < nslR; ++sl) s += sPart[sl * RM + tid];
+            sZ[tid] = s;
+            if (a.st_read) a.st_read[bt * RM + tid] = s;
+        }
+        __syncthreads();
+    }
+
+    // ---- final state
+    for (int i = tid; i < N * Md; i += T) a.M_out[(size_t)b * N * Md + i] = sM[(i / Md) * MP + (i % Md)];
+    for (int i = tid; i < H * N; i += T) a.w_out[(size_t)b * H * N + i] = sW[i];
+    for (int i = tid; i < RM; i += T) a.read_out[(size_t)b * RM + i] = sZ[i];
+    for (int i = tid; i < hid; i += T) {
+        a.cs_out[(size_t)b * 2 * hid + i] = sC[i];
+        a.cs_out[(size_t)b * 2 * hid + hid + i] = sZ[RM + i];
+    }
+}
+
+// pick the workgroup size: whole waves, enough threads for N slots x >=1 head, hid units + Md columns
+static int ntm_pick_threads(const NtmDims& d) {
+    int want = ntm_imax(d.H * d.N, 3 * d.hid);
+    want = ntm_imax(want, d.hid + ntm_imax(d.Md, 4));
+    want = ntm_imax(want, d.PP + d.Md);
+    want = ntm_imax(want, d.H * d.Md + d.H + 1);
+    want = ((want + 63) / 64) * 64;
+    if (want > 1024) want = 1024;
+    return want;
+}
+
+int ntm_validate_dims(const NtmDims& d, const char* who) {
+    NTK_REQUIRE(d.B > 0 && d.S > 0, NTK_ERR_BAD_SHAPE, "%s: B=%d S=%d", who, d.B, d.S);
+    NTK_REQUIRE(d.N >= 64 && (d.N % 64) == 0 && d.N <= 1024, NTK_ERR_UNSUPPORTED,
+                "%s: mem_size=%d must be a multiple of 64 in [64,1024]", who, d.N);
+    NTK_REQUIRE(d.Md >= 1 && d.Md <= 256, NTK_ERR_UNSUPPORTED, "%s: mem_dim=%d out of range", who, d.Md);
+    NTK_REQUIRE(d.R >= 1 && d.Wh >= 1, NTK_ERR_BAD_SHAPE, "%s: need >=1 read and write head (R=%d W=%d)", who, d.R, d.Wh);
+    NTK_REQUIRE(d.hid >= 1 && d.hid + d.Md <= 1024 && d.PP + d.Md <= 1024 && d.H * d.Md + d.H + 1 <= 1024 &&
+                    d.R * d.Md <= 1024,
+                NTK_ERR_UNSUPPORTED, "%s: hidden=%d heads=%d mem_dim=%d exceed one workgroup", who, d.hid, d.H, d.Md);
+    NTK_REQUIRE(d.SS >= 1 && d.SS < d.N && d.O >= 1, NTK_ERR_BAD_SHAPE, "%s: shift space %d / output_dim %d", who, d.SS, d.O);
+    return NTK_OK;
+}
+
+extern "C" int ntk_ntm_padded_dims(int N, int Md, int R, int Wh, int hid, int shift_range, int O,
+                                   int* P, int* PP, int* K, int* ldz, int* ldh) {
+    NtmDims d;
+    ntm_fill_dims(d, 1, 1, N, Md, R, Wh, hid, shift_range, O, 0);
+    if (P) *P = d.P;
+    if (PP) *PP = d.PP;
+    if (K) *K = d.K;
+    if (ldz) *ldz = d.ldz;
+    if (ldh) *ldh = d.ldh;
+    return NTK_OK;
+}
+
+extern "C" int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int hid, int shift_range, int O,
+                               int write_first,
+                               const float* xproj, const float* Wr, const float* Wa,
+                               const float* M0, const float* w0, const float* read0, const float* cs0,
+                               float* logits, float* outputs,
+                               float* M_out, float* w_out, float* read_out, float* cs_out,
+                               float* st_z, float* st_gates, float* st_c, float* st_h, float* st_u,
+                               float* st_wc, float* st_wv, float* st_w, float* st_M, float* st_read,
+                               void* stream) {
+    NtmFwdArgs a;
+    ntm_fill_dims(a.d, B, S, N, Md, R, Wh, hid, shift_range, O, write_first);
+    int rc = ntm_validate_dims(a.d, "ntk_ntm_seq_fwd");
+    if (rc != NTK_OK) return rc;
+    NTK_REQUIRE(xproj && Wr && Wa && M0 && w0 && read0 && cs0 && logits && M_out && w_out && read_out && cs_out,
+                NTK_ERR_BAD_PTR, "ntk_ntm_seq_fwd: null pointer");
+    NTK_REQUIRE(ntk_aligned16(xproj) && ntk_aligned16(Wr) && ntk_aligned16(Wa) &&
+                    (!st_gates || ntk_aligned16(st_gates)),
+                NTK_ERR_BAD_PTR, "ntk_ntm_seq_fwd: xproj/Wr/Wa/st_gates must be 16-byte aligned");
+    const bool any = st_z || st_gates || st_c || st_h || st_u || st_wc || st_wv || st_w || st_M || st_read;
+    NTK_REQUIRE(!st_gates == !st_c, NTK_ERR_BAD_PTR, "ntk_ntm_seq_fwd: st_gates and st_c go together");
+    (void)any;
+    a.xproj = xproj; a.Wr = Wr; a.Wa = Wa; a.M0 = M0; a.w0 = w0; a.read0 = read0; a.cs0 = cs0;
+    a.logits = logits; a.outputs = outputs; a.M_out = M_out; a.w_out = w_out; a.read_out = read_out; a.cs_out = cs_out;
+    a.st_z = st_z; a.st_gates = st_gates; a.st_c = st_c; a.st_h = st_h; a.st_u = st_u;
+    a.st_wc = st_wc; a.st_wv = st_wv; a.st_w = st_w; a.st_M = st_M; a.st_read = st_read;
+    const int T = ntm_pick_threads(a.d);
+    NTK_REQUIRE(T >= a.d.N, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_fwd: mem_size %d exceeds the workgroup", a.d.N);
+    NtmLds L;
+    ntm_fwd_lds(a.d, T, L);
+    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED,
+                "ntk_ntm_seq_fwd: state needs %zu B of LDS (> 160 KiB)", lds_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ntk_set_error("ntk_ntm_seq_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
+        attr_set = true;
+    }
+    ntm_seq_fwd_kernel<<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    NTK_CHECK_LAUNCH("ntk_ntm_seq_fwd");
+    return NTK_OK;
+}

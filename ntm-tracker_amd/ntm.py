@@ -1,0 +1,333 @@
+"""NTMCell / LoopNTMTracker on the HIP sequence kernels.
+
+Mirrors the reference operator interface:
+  * ``NTMCell(output_dim, mem_size, mem_dim, shift_range, controller_hidden_size,
+    controller_num_layers, write_head_size, read_head_size, write_first)``
+    (ntm_cell.py:18-20), ``cell(inputs, prev_state, M_prev=..., w_prev=...,
+    read_prev=..., controller_state=...)`` returning the reference's 8-tuple
+    (ntm_cell.py:252-253), ``zero_state`` (:284-315), ``state_placeholder``
+    (:255-282);
+  * ``LoopNTMTracker(sequence_length, output_dim, initializer, **cell_kwargs)
+    (inputs[B,S,D], state=None) -> (outputs, output_logits)``
+    (ntm_tracker_new.py:5-49).
+State lives in device tensors; every arithmetic step runs in
+libntmtrack_hip.so (no torch math on the path, no CPU fallback).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_P = _lib.ptr
+
+
+def _np(t):
+    return None if t is None else _lib.ptr(t)
+
+
+class NTMDims(object):
+    def __init__(self, input_dim, output_dim, mem_size, mem_dim, shift_range, hidden, read_heads, write_heads):
+        self.D = int(input_dim)
+        self.O = int(output_dim)
+        self.N, self.Md = int(mem_size), int(mem_dim)
+        self.R, self.Wh = int(read_heads), int(write_heads)
+        self.H = self.R + self.Wh
+        self.hid = int(hidden)
+        self.shift_range = int(shift_range)
+        self.SS = 2 * self.shift_range + 1
+        vals = [ctypes.c_int() for _ in range(5)]
+        _lib.check(_lib.lib().ntk_ntm_padded_dims(self.N, self.Md, self.R, self.Wh, self.hid, self.shift_range,
+                                                  self.O, *[ctypes.byref(v) for v in vals]), "ntk_ntm_padded_dims")
+        self.P, self.PP, self.K, self.ldz, self.ldh = [v.value for v in vals]
+        self.ldx = (self.D + 3) // 4 * 4
+        self.RM = self.R * self.Md
+        # control offsets (ntm_cell.py:128-130)
+        self.oK = 0
+        self.oB = self.H * self.Md
+        self.oG = self.oB + self.H
+        self.oS = self.oG + self.H
+        self.oY = self.oS + self.H * self.SS
+        self.oE = self.oY + self.H
+        self.oA = self.oE + self.Wh * self.Md
+
+
+class PackedParams(object):
+    """Flat fp32 master copy of the trainable parameters in kernel layout
+    (see csrc/ntm_common.h) with named views, plus a same-shaped gradient."""
+
+    def __init__(self, dims, device):
+        d = dims
+        self.dims = d
+        self.shapes = [
+            ("WxT", (4 * d.hid, d.ldx)),
+            ("Wr", (d.ldz, 4 * d.hid)),
+            ("Wa", (d.ldh, d.PP)),
+            ("V_M", (d.N, d.Md)),
+            ("V_w", (d.H, d.N)),
+            ("V_r", (d.R, d.Md)),
+        ]
+        n = 0
+        self.offsets = {}
+        for name, shp in self.shapes:
+            sz = 1
+            for s in shp:
+                sz *= s
+            n = (n + 3) // 4 * 4          # keep every view 16-byte aligned
+            self.offsets[name] = (n, sz, shp)
+            n += sz
+        self.numel = (n + 3) // 4 * 4
+        self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
+
+    def view(self, name, grad=False):
+        o, sz, shp = self.offsets[name]
+        return (self.grad if grad else self.flat)[o:o + sz].view(shp)
+
+    # ---- conversion from / to the reference's TF variable layout
+    def load_tf(self, sd):
+        d = self.dims
+        W = torch.as_tensor(sd["lstm/cell_0/weights"], dtype=torch.float32)
+        b = torch.as_tensor(sd["lstm/cell_0/biases"], dtype=torch.float32)
+        assert tuple(W.shape) == (d.D + d.RM + d.hid, 4 * d.hid), W.shape
+        # gate-major columns g*hid+j  ->  unit-major n' = j*4+g
+        perm = torch.arange(4 * d.hid).view(4, d.hid).t().reshape(-1)
+        Wp = W[:, perm]
+        bp = b[perm]
+        WxT = torch.zeros((4 * d.hid, d.ldx))
+        WxT[:, :d.D] = Wp[:d.D].t()
+        Wr = torch.zeros((d.ldz, 4 * d.hid))
+        Wr[:d.K] = Wp[d.D:]
+        Wr[d.K] = bp
+        Wa = torch.zeros((d.ldh, d.PP))
+        Wa[:d.hid, :d.P] = torch.as_tensor(sd["addressing/weights"], dtype=torch.float32)
+        Wa[:d.hid, d.P:d.P + d.O] = torch.as_tensor(sd["output/weights"], dtype=torch.float32)
+        Wa[d.hid, :d.P] = torch.as_tensor(sd["addressing/biases"], dtype=torch.float32)
+        Wa[d.hid, d.P:d.P + d.O] = torch.as_tensor(sd["output/biases"], dtype=torch.float32)
+        dev = self.flat.device
+        self.view("WxT").copy_(WxT.to(dev))
+        self.view("Wr").copy_(Wr.to(dev))
+        self.view("Wa").copy_(Wa.to(dev))
+        self.view("V_M").copy_(torch.as_tensor(sd["init_state/M"], dtype=torch.float32).to(dev))
+        self.view("V_w").copy_(torch.as_tensor(sd["init_state/w"], dtype=torch.float32).to(dev))
+        self.view("V_r").copy_(torch.as_tensor(sd["init_state/read"], dtype=torch.float32).to(dev))
+
+    def to_tf(self, grad=False):
+        d = self.dims
+        WxT = self.view("WxT", grad).cpu()
+        Wr = self.view("Wr", grad).cpu()
+        Wa = self.view("Wa", grad).cpu()
+        inv = torch.arange(4 * d.hid).view(d.hid, 4).t().reshape(-1)   # gate-major col g*hid+j <- n' = j*4+g
+        Wp = torch.cat([WxT[:, :d.D].t(), Wr[:d.K]], dim=0)
+        return {
+            "lstm/cell_0/weights": Wp[:, inv].contiguous(),
+            "lstm/cell_0/biases": Wr[d.K][inv].contiguous(),
+            "addressing/weights": Wa[:d.hid, :d.P].contiguous(),
+            "addressing/biases": Wa[d.hid, :d.P].contiguous(),
+            "output/weights": Wa[:d.hid, d.P:d.P + d.O].contiguous(),
+            "output/biases": Wa[d.hid, d.P:d.P + d.O].contiguous(),
+            "init_state/M": self.view("V_M", grad).cpu().clone(),
+            "init_state/w": self.view("V_w", grad).cpu().clone(),
+            "init_state/read": self.view("V_r", grad).cpu().clone(),
+        }
+
+
+def gemm_nt(A, B, bias=None, out=None):
+    """out[M,N] = A[M,K] @ B[N,K]^T (+bias) on the fp32 MFMA kernel."""
+    M, K = A.shape
+    N, K2 = B.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ntk_gemm_nt_f32(_P(A), A.stride(0), _P(B), B.stride(0), _np(bias), _P(out), out.stride(0),
+                                          M, N, K, _lib.stream()), "ntk_gemm_nt_f32")
+    return out
+
+
+def gemm_tn(A, B, out, accumulate=False, splits=None, workspace=None):
+    """out[M,N] (+)= A[K,M]^T @ B[K,N] on the fp32 MFMA kernel (fixed-order split-K)."""
+    K, M = A.shape
+    K2, N = B.shape
+    assert K == K2 and tuple(out.shape) == (M, N)
+    if splits is None:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splits = max(1, min((K + 255) // 256, (1024 + tiles - 1) // tiles))
+    L = _lib.lib()
+    need = L.ntk_gemm_tn_workspace_bytes(M, N, splits) // 4
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=A.device, dtype=torch.float32)
+    _lib.check(L.ntk_gemm_tn_f32(_P(A), A.stride(0), _P(B), B.stride(0), _P(out), out.stride(0), M, N, K, splits,
+                                 1 if accumulate else 0, _P(workspace), _lib.stream()), "ntk_gemm_tn_f32")
+    return out
+
+
+class NTMCell(object):
+    """The NTM recurrent cell (ntm_cell.py:17-315) on the HIP path."""
+
+    def __init__(self, output_dim, mem_size=128, mem_dim=20, shift_range=1,
+                 controller_hidden_size=100, controller_num_layers=10,
+                 write_head_size=3, read_head_size=3, write_first=False,
+                 input_dim=None, device="cuda", init_scale=0.1, seed=None):
+        if controller_num_layers != 1:
+            raise _lib.NtkError("controller_num_layers=%d: the HIP path implements the single-layer controller "
+                                "the reference scripts run (direct_offset_output.py:24)" % controller_num_layers)
+        self.mem_size = mem_size
+        self.mem_dim = mem_dim
+        self.controller_hidden_size = controller_hidden_size
+        self.controller_num_layers = controller_num_layers
+        self.write_head_size = write_head_size
+        self.read_head_size = read_head_size
+        self.shift_range = shift_range
+        self.output_dim = output_dim
+        self.write_first = bool(write_first)
+        self.device = torch.device(device)
+        self.init_scale = init_scale
+        self.seed = seed
+        self.dims = None
+        self.params = None
+        if input_dim is not None:
+            self._build(input_dim)
+
+    # ---- parameters
+    def _build(self, input_dim, tf_state_dict=None):
+        self.dims = NTMDims(input_dim, self.output_dim, self.mem_size, self.mem_dim, self.shift_range,
+                            self.controller_hidden_size, self.read_head_size, self.write_head_size)
+        self.params = PackedParams(self.dims, self.device)
+        if tf_state_dict is None:
+            d = self.dims
+            g = torch.Generator().manual_seed(0 if self.seed is None else int(self.seed))
+            s = self.init_scale
+            u = lambda *shape: (torch.rand(shape, generator=g) * 2 - 1) * s
+            tf_state_dict = {
+                "lstm/cell_0/weights": u(d.D + d.RM + d.hid, 4 * d.hid),
+                "lstm/cell_0/biases": torch.zeros(4 * d.hid),
+                "addressing/weights": u(d.hid, d.P), "addressing/biases": torch.zeros(d.P),
+                "output/weights": u(d.hid, d.O), "output/biases": torch.zeros(d.O),
+                "init_state/M": u(d.N, d.Md), "init_state/w": u(d.H, d.N), "init_state/read": u(d.R, d.Md),
+            }
+        self.params.load_tf(tf_state_dict)
+
+    def load_state_dict(self, sd, input_dim=None):
+        if input_dim is None:
+            input_dim = sd["lstm/cell_0/weights"].shape[0] - self.read_head_size * self.mem_dim - self.controller_hidden_size
+        self._build(int(input_dim), sd)
+
+    def state_dict(self):
+        return self.params.to_tf()
+
+    # ---- state helpers
+    def zero_state(self, batch_size, initializer=None):
+        """ntm_cell.py:284-315: M0=tanh(V_M), w0=sigmoid(V_w) (un-normalised), read0=tanh(V_r), LSTM state 0."""
+        d, dev, L = self.dims, self.device, _lib.lib()
+        if d is None:
+            raise _lib.NtkError("zero_state before the cell has parameters: pass input_dim= or load_state_dict()")
+        st = self.state_placeholder(batch_size)
+        for name, key, act in (("V_M", "M", 0), ("V_w", "w", 1), ("V_r", "read", 0)):
+            v = self.params.view(name)
+            _lib.check(L.ntk_ntm_init_state(_P(v), _P(st[key]), v.numel(), batch_size, act, _lib.stream()),
+                       "ntk_ntm_init_state")
+        st["controller_state"].zero_()
+        return st
+
+    def state_placeholder(self, batch_size):
+        d, dev = self.dims, self.device
+        return {
+            "M": torch.empty((batch_size, d.N, d.Md), device=dev),
+            "w": torch.empty((batch_size, d.H, d.N), device=dev),
+            "read": torch.empty((batch_size, d.R, d.Md), device=dev),
+            "controller_state": torch.empty((batch_size, 2 * d.hid), device=dev),
+        }
+
+    # ---- sequence kernel
+    def _pad_inputs(self, inputs):
+        d = self.dims
+        B, S, D = inputs.shape
+        if D == d.ldx and inputs.is_contiguous():
+            return inputs                      # already in kernel layout (serialiser output, zero padded)
+        if D != d.D:
+            raise _lib.NtkError("inputs have %d features, the cell was built for %d" % (D, d.D))
+        X = torch.zeros((B, S, d.ldx), device=self.device, dtype=torch.float32)
+        X[:, :, :D] = inputs
+        return X
+
+    def run_sequence(self, X, state, record=False, want_outputs=True):
+        """X [B,S,ldx] (zero padded beyond D).  Returns (logits, outputs, new_state, record dict)."""
+        d, dev = self.dims, self.device
+        B, S, ldx = X.shape
+        assert ldx == d.ldx
+        xproj = gemm_nt(X.view(B * S, ldx), self.params.view("WxT"))
+        logits = torch.empty((B, S, d.O), device=dev)
+        outputs = torch.empty((B, S, d.O), device=dev) if want_outputs else None
+        new = self.state_placeholder(B)
+        rec = {}
+        if record:
+            rec = {
+                "z": torch.empty((B, S, d.ldz), device=dev), "gates": torch.empty((B, S, d.hid, 4), device=dev),
+                "c": torch.empty((B, S, d.hid), device=dev), "h": torch.empty((B, S, d.ldh), device=dev),
+                "u": torch.empty((B, S, d.PP), device=dev), "wc": torch.empty((B, S, d.H, d.N), device=dev),
+                "wv": torch.empty((B, S, d.H, d.N), device=dev), "w": torch.empty((B, S, d.H, d.N), device=dev),
+                "M": torch.empty((B, S, d.N, d.Md), device=dev), "read": torch.empty((B, S, d.R, d.Md), device=dev),
+            }
+        g = lambda k: _np(rec.get(k))
+        _lib.check(_lib.lib().ntk_ntm_seq_fwd(
+            B, S, d.N, d.Md, d.R, d.Wh, d.hid, d.shift_range, d.O, 1 if self.write_first else 0,
+            _P(xproj), _P(self.params.view("Wr")), _P(self.params.view("Wa")),
+            _P(state["M"].contiguous()), _P(state["w"].contiguous()), _P(state["read"].contiguous()),
+            _P(state["controller_state"].contiguous()),
+            _P(logits), _np(outputs), _P(new["M"]), _P(new["w"]), _P(new["read"]), _P(new["controller_state"]),
+            g("z"), g("gates"), g("c"), g("h"), g("u"), g("wc"), g("wv"), g("w"), g("M"), g("read"),
+            _lib.stream()), "ntk_ntm_seq_fwd")
+        rec["xproj"] = xproj
+        return logits, outputs, new, rec
+
+    # ---- the reference step() API
+    def __call__(self, inputs, prev_state, M_prev=None, w_prev=None, read_prev=None,
+                 controller_state=None, scope=None):
+        """One step; returns (ntm_output, ntm_output_logit, state, debug, M, w, read, controller_state)
+        exactly as ntm_cell.py:252-253."""
+        if self.dims is None:
+            self._build(inputs.shape[1])
+        d = self.dims
+        if prev_state is not None:
+            M_prev, w_prev = prev_state["M"], prev_state["w"]
+            read_prev, controller_state = prev_state["read"], prev_state["controller_state"]
+        st = {"M": M_prev, "w": w_prev, "read": read_prev, "controller_state": controller_state}
+        X = self._pad_inputs(inputs.unsqueeze(1))
+        logits, outputs, new, rec = self.run_sequence(X, st, record=True)
+        u = rec["u"][:, 0]
+        B = inputs.shape[0]
+        H, Md, R = d.H, d.Md, d.R
+        w = rec["w"][:, 0]
+        debug = {   # ntm_cell.py:230-250 (the reference's key 'bega' is kept)
+            "k": u[:, d.oK:d.oB].reshape(B, H, Md), "bega": u[:, d.oB:d.oG].unsqueeze(-1),
+            "g": u[:, d.oG:d.oS].unsqueeze(-1), "gamma": u[:, d.oY:d.oE].unsqueeze(-1),
+            "erase": u[:, d.oE:d.oA].reshape(B, d.Wh, Md), "add": u[:, d.oA:d.P].reshape(B, d.Wh, Md),
+            "w_content_focused": rec["wc"][:, 0], "w_conv": rec["wv"][:, 0],
+            "w": w, "w_read": w[:, :R], "w_write": w[:, R:], "M": new["M"], "M_prev": M_prev,
+        }
+        state = {"M": new["M"], "w": new["w"], "read": new["read"], "controller_state": new["controller_state"]}
+        return (outputs[:, 0], logits[:, 0], state, debug, new["M"], new["w"], new["read"], new["controller_state"])
+
+    step = __call__
+
+
+class LoopNTMTracker(object):
+    """ntm_tracker_new.py:4-64: unroll the cell over [B,S,D] inputs.  The
+    tf.while_loop becomes one persistent kernel launch."""
+
+    def __init__(self, sequence_length, output_dim, initializer=None, **kwargs):
+        self.cell = NTMCell(output_dim, **kwargs)
+        self.initializer = initializer
+        self.sequence_length = sequence_length
+
+    def __call__(self, inputs, state=None, scope=None, record=False):
+        B, S, D = inputs.shape
+        if S != self.sequence_length:
+            raise _lib.NtkError("inputs have %d steps, tracker was built for %d" % (S, self.sequence_length))
+        if self.cell.dims is None:
+            self.cell._build(D)
+        X = self.cell._pad_inputs(inputs)
+        state = state or self.cell.zero_state(B, self.initializer)
+        logits, outputs, new, rec = self.cell.run_sequence(X, state, record=record)
+        self.last_state, self.last_record = new, rec
+        return outputs, logits

@@ -1,0 +1,124 @@
+"""GPU parity: NTM sequence kernel + tracking head vs the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ntm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(cfg_kwargs, D, O_dim, seed, scale=0.05):
+    cfg = O.NTMConfig(D, O_dim, **cfg_kwargs)
+    rng = np.random.default_rng(seed)
+    params = O.init_params(cfg, rng, scale=scale)
+    # non-zero biases so the bias path is exercised
+    for k in params:
+        if k.endswith("biases"):
+            params[k] = rng.uniform(-scale, scale, size=params[k].shape).astype(np.float32)
+    return cfg, params, rng
+
+
+def _cell(cfg, params, cuda):
+    from ntmtrack.ntm import NTMCell
+    cell = NTMCell(cfg.output_dim, mem_size=cfg.mem_size, mem_dim=cfg.mem_dim, shift_range=cfg.shift_range,
+                   controller_hidden_size=cfg.hidden, controller_num_layers=1,
+                   write_head_size=cfg.write_heads, read_head_size=cfg.read_heads,
+                   write_first=cfg.write_first, device=cuda)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, input_dim=cfg.input_dim)
+    return cell
+
+
+CASES = [
+    # (name, cfg kwargs, D, S, B)
+    ("c2_r4w1", dict(mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=200, controller_num_layers=1,
+                     write_head_size=1, read_head_size=4), 514, 12, 3),
+    ("c1_copy_r1w1", dict(mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=100, controller_num_layers=1,
+                          write_head_size=1, read_head_size=1), 4, 41, 2),
+    ("write_first_multiwrite", dict(mem_size=64, mem_dim=8, shift_range=2, controller_hidden_size=96,
+                                    controller_num_layers=1, write_head_size=2, read_head_size=3, write_first=True), 10, 7, 2),
+    ("batch1_odd_dims", dict(mem_size=192, mem_dim=13, shift_range=1, controller_hidden_size=77, controller_num_layers=1,
+                             write_head_size=1, read_head_size=2), 9, 5, 1),
+]
+
+
+@pytest.mark.parametrize("name,kw,D,S,B", CASES, ids=[c[0] for c in CASES])
+def test_sequence_matches_oracle(cuda, name, kw, D, S, B):
+    cfg, params, rng = _mk(kw, D, 2, seed=11)
+    x = rng.standard_normal((B, S, D)).astype(np.float32)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    outs, logits, fin, states = O.loop_ntm_tracker(cfg, p64, x.astype(np.float64), return_states=True)
+
+    from ntmtrack.ntm import LoopNTMTracker
+    cell = _cell(cfg, params, cuda)
+    trk = LoopNTMTracker.__new__(LoopNTMTracker)
+    trk.cell, trk.initializer, trk.sequence_length = cell, None, S
+    o_gpu, l_gpu = trk(torch.from_numpy(x).to(cuda), record=True)
+    torch.cuda.synchronize()
+    # north_star tolerance 1e-4 (fp32); observed error is ~1e-6
+    np.testing.assert_allclose(l_gpu.cpu().numpy(), logits, atol=2e-5, rtol=0)
+    np.testing.assert_allclose(o_gpu.cpu().numpy(), outs, atol=2e-5, rtol=0)
+    for key in ("M", "w", "read", "controller_state"):
+        np.testing.assert_allclose(trk.last_state[key].cpu().numpy(), fin[key], atol=2e-5, rtol=0, err_msg=key)
+    # per-step records (what the reference's TensorArrays Ms/ws/reads hold, ntm_tracker_new.py:59-61)
+    rec = trk.last_record
+    for t in (0, S // 2, S - 1):
+        np.testing.assert_allclose(rec["M"][:, t].cpu().numpy(), states[t]["M"], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(rec["w"][:, t].cpu().numpy(), states[t]["w"], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(rec["read"][:, t].cpu().numpy(), states[t]["read"], atol=2e-5, rtol=0)
+
+
+def test_step_api_8tuple_and_debug(cuda):
+    """cell(inputs, prev_state) with a state dict (the test_tracker.py:340-341 form) and with
+    keyword state (the LoopNTMTracker form, ntm_tracker_new.py:54-56) agree with the oracle step."""
+    kw = CASES[0][1]
+    cfg, params, rng = _mk(kw, 514, 2, seed=5)
+    B = 2
+    x = rng.standard_normal((B, 514)).astype(np.float32)
+    st = O.zero_state(cfg, params, B)
+    # perturb the state so it is not the broadcast initial one
+    st = {k: (v + rng.uniform(0, 0.05, size=v.shape)).astype(np.float32) for k, v in st.items()}
+    out, logit, new, dbg = O.ntm_step(cfg, params, x, st)
+    cell = _cell(cfg, params, cuda)
+    tst = {k: torch.from_numpy(v).to(cuda) for k, v in st.items()}
+    res = cell(torch.from_numpy(x).to(cuda), tst)
+    assert len(res) == 8
+    o, l, state, debug, M, w, read, cs = res
+    res2 = cell(torch.from_numpy(x).to(cuda), None, M_prev=tst["M"], w_prev=tst["w"], read_prev=tst["read"],
+                controller_state=tst["controller_state"])
+    torch.cuda.synchronize()
+    for a, b_ in zip((o, l, M, w, read, cs), (res2[0], res2[1], res2[4], res2[5], res2[6], res2[7])):
+        assert torch.equal(a, b_)
+    np.testing.assert_allclose(l.cpu().numpy(), logit, atol=1e-5)
+    np.testing.assert_allclose(o.cpu().numpy(), out, atol=1e-5)
+    np.testing.assert_allclose(M.cpu().numpy(), new["M"], atol=1e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), new["w"], atol=1e-5)
+    np.testing.assert_allclose(read.cpu().numpy(), new["read"], atol=1e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), new["controller_state"], atol=1e-5)
+    assert set(state.keys()) == {"M", "w", "read", "controller_state"}
+    for key, okey in (("k", "k"), ("bega", "beta"), ("g", "g"), ("gamma", "gamma"), ("erase", "erase"),
+                      ("add", "add"), ("w_content_focused", "w_content_focused"), ("w_conv", "w_conv"), ("w", "w")):
+        np.testing.assert_allclose(debug[key].cpu().numpy(), dbg[okey], atol=1e-5, err_msg=key)
+
+
+def test_zero_state_matches_oracle(cuda):
+    kw = CASES[0][1]
+    cfg, params, rng = _mk(kw, 514, 2, seed=3)
+    cell = _cell(cfg, params, cuda)
+    st = cell.zero_state(4)
+    ref = O.zero_state(cfg, params, 4)
+    torch.cuda.synchronize()
+    for k in ref:
+        np.testing.assert_allclose(st[k].cpu().numpy(), ref[k], atol=1e-6, err_msg=k)
+
+
+def test_unsupported_configs_fail_loudly(cuda):
+    from ntmtrack.ntm import NTMCell
+    from ntmtrack._lib import NtkError
+    with pytest.raises(NtkError):
+        NTMCell(2, controller_num_layers=10, device=cuda)          # reference default; HIP path is single-layer
+    cell = NTMCell(2, mem_size=100, mem_dim=20, controller_hidden_size=64, controller_num_layers=1,
+                   write_head_size=1, read_head_size=1, input_dim=8, device=cuda)
+    with pytest.raises(NtkError):                                   # mem_size must be a multiple of 64
+        st = cell.zero_state(1)
+        cell(torch.zeros((1, 8), device=cuda), st)
