@@ -32,6 +32,8 @@ def _sig(lib):
         "ntk_gemm_tn_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
         "ntk_ntm_padded_dims": (c_int, [c_int] * 7 + [ctypes.POINTER(c_int)] * 5),
         "ntk_ntm_seq_fwd": (c_int, [c_int] * 10 + [P] * 23 + [P]),
+        "ntk_transpose_pad": (c_int, [P, c_int, P, c_int, c_int, c_int, P]),
+        "ntk_ntm_seq_bwd": (c_int, [c_int] * 10 + [P, c_int, P, c_int] + [P] * 21 + [P]),
         "ntk_gather_serialize": (c_int, [P, P, P] + [c_int] * 9 + [P]),
         "ntk_offset_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_ntm_init_state": (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -1,0 +1,533 @@
+// NTM sequence backward (full BPTT, no truncation -- what tf.gradients through
+// the tf.while_loop of LoopNTMTracker computes, direct_offset_output.py:611-621).
+// One persistent workgroup per sequence walks the steps in reverse with the
+// carried gradients (dM, dw, dread, dh, dc) resident in LDS.  The forward pass
+// recorded every tensor the step derivative needs (ntm_seq_fwd.hip), so nothing
+// is recomputed except cheap elementwise terms; the next step's records are
+// prefetched into registers while the current step computes.
+//
+// Outputs: per-step raw (pre-activation) gradients of the LSTM gates and of the
+// unpack/output linear -- the weight gradients are then three k-major GEMMs over
+// all B*S rows (ntk_gemm_tn_f32) -- and the gradient of the initial state.
+//
+// Gradient semantics: pow: d/dx = y*x^(y-1), d/dy = x^y*log(x)
+// with log(x) -> 0 for x <= 0; l2_normalize differentiates through
+// rsqrt(max(sum x^2, 1e-12)) (zero through the norm when clamped).
+#include "ntm_common.h"
+
+struct NtmBwdArgs {
+    NtmDims d;
+    const float* WrT;      // [4*hid][ldkT]  transposed recurrent weights (rows n' = unit*4+gate)
+    const float* WaT;      // [PP][ldhT]     transposed unpack/output weights
+    int ldkT, ldhT;
+    const float* M0; const float* w0; const float* cs0;
+    const float* st_gates; const float* st_c; const float* st_u;
+    const float* st_wc; const float* st_wv; const float* st_w; const float* st_M;
+    const float* dlogits;  // [B,S,O]
+    const float* dM_fin; const float* dw_fin; const float* dread_fin; const float* dcs_fin;  // nullable
+    float* dgates;         // [B,S,4*hid]
+    float* du;             // [B,S,PP]
+    float* dM0; float* dw0; float* dread0; float* dcs0;
+};
+
+struct NtmBwdLds {
+    int part, dM, G, Mp, Mt, dW, Wp, Wt, Wc, Wv, Wg, Dwv, Dsim, U, DU, DG, dZ, dC, Gt, Ct, Cp,
+        Khat, Ks, Kinv, Kss, Cinv, Css, C2, Dkhat, Sw, Red, total;
+};
+
+constexpr int NQ = 6;        // max simultaneous per-head reductions in one stage
+constexpr int NQT = 11;      // reduction slots per head; every stage owns its own slots (no read/write reuse inside a step)
+constexpr int QR1 = 0, QR2 = 2, QR3 = 8, QR4 = 10;
+constexpr int MAXM = 8;      // max memory elements prefetched per thread
+
+static void ntm_bwd_lds(const NtmDims& d, int T, int ldkT, int ldhT, NtmBwdLds& L) {
+    const int MP = d.Md | 1, NM = d.N * MP, HN = d.H * d.N;
+    const int nout = d.H * d.Md + d.Md + 2 * d.Wh * d.Md;
+    const int nslP = ntm_imin(ntm_imax(1, T / nout), d.N);
+    const int nslZ = ntm_imax(1, T / (ldkT / 4));
+    const int nslH = ntm_imax(1, T / (ldhT / 4));
+    const int nslC = ntm_imax(1, T / d.Md);
+    int part = ntm_imax(nslP * nout, nslZ * ldkT);
+    part = ntm_imax(part, nslH * ldhT);
+    part = ntm_imax(part, nslC * d.Md);
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += ntm_align4(n); return r; };
+    L.part = take(part);
+    L.dM = take(NM); L.G = take(NM); L.Mp = take(NM); L.Mt = take(d.write_first ? NM : 4);
+    L.dW = take(HN); L.Wp = take(HN); L.Wt = take(HN); L.Wc = take(HN); L.Wv = take(HN); L.Wg = take(HN);
+    L.Dwv = take(HN); L.Dsim = take(HN);
+    L.U = take(d.PP); L.DU = take(d.PP); L.DG = take(4 * d.hid); L.dZ = take(ldkT); L.dC = take(d.hid);
+    L.Gt = take(4 * d.hid); L.Ct = take(d.hid); L.Cp = take(d.hid);
+    L.Khat = take(d.H * d.Md); L.Ks = take(d.H * d.Md); L.Kinv = take(d.H); L.Kss = take(d.H);
+    L.Cinv = take(d.Md); L.Css = take(d.Md); L.C2 = take(d.Md); L.Dkhat = take(d.H * d.Md);
+    L.Sw = take(d.H * d.SS);
+    L.Red = take(d.H * NQT * (d.N / 64));
+    L.total = o;
+}
+
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdLds L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NtmDims& d = a.d;
+    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+    const int N = d.N, Md = d.Md, MP = d.Md | 1, R = d.R, Wh = d.Wh, H = d.H, hid = d.hid;
+    const int S = d.S, K = d.K, PP = d.PP, RM = R * Md, SS = d.SS, NW = N >> 6, NMd = N * Md, HN = H * N;
+    const bool wf = d.write_first != 0;
+
+    float* sPart = smem + L.part;
+    float* sdM = smem + L.dM;  float* sG = smem + L.G;  float* sMp = smem + L.Mp;  float* sMt = smem + L.Mt;
+    float* sdW = smem + L.dW;  float* sWp = smem + L.Wp; float* sWt = smem + L.Wt; float* sWc = smem + L.Wc;
+    float* sWv = smem + L.Wv;  float* sWg = smem + L.Wg; float* sDwv = smem + L.Dwv; float* sDsim = smem + L.Dsim;
+    float* sU = smem + L.U;    float* sDU = smem + L.DU; float* sDG = smem + L.DG; float* sdZ = smem + L.dZ;
+    float* sdC = smem + L.dC;  float* sGt = smem + L.Gt; float* sCt = smem + L.Ct; float* sCp = smem + L.Cp;
+    float* sKhat = smem + L.Khat; float* sKs = smem + L.Ks; float* sKinv = smem + L.Kinv; float* sKss = smem + L.Kss;
+    float* sCinv = smem + L.Cinv; float* sCss = smem + L.Css; float* sC2 = smem + L.C2; float* sDkhat = smem + L.Dkhat;
+    float* sSw = smem + L.Sw;  float* sRed = smem + L.Red;
+    f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
+
+    // thread roles
+    const int hh = tid / N, nn = tid - hh * N;          // (head, slot) owner; active iff hh < H
+    const bool hn = hh < H;
+    const int wi = nn >> 6;
+    const int nout = H * Md + Md + 2 * Wh * Md;
+    const int nslP = min(max(1, T / nout), N);
+    const int nperP = (N + nslP - 1) / nslP;
+    const int kg4 = a.ldkT >> 2, hg4 = a.ldhT >> 2;
+    const int nslZ = max(1, T / kg4), nperZ = (4 * hid + nslZ - 1) / nslZ;
+    const int nslH = max(1, T / hg4), nperH = (PP + nslH - 1) / nslH;
+    const int nslC = max(1, T / Md), nperC = (N + nslC - 1) / nslC;
+
+    // ---- prefetch registers for one step's records
+    float pM[MAXM], pMt[MAXM], pWp = 0.f, pWt = 0.f, pWc = 0.f, pWv = 0.f, pU = 0.f, pCt = 0.f, pCp = 0.f, pDl = 0.f;
+    f32x4 pG = {0.f, 0.f, 0.f, 0.f};
+    auto prefetch = [&](int t) {
+        const size_t bt = (size_t)b * S + t;
+        const float* Mp = (t > 0) ? a.st_M + (bt - 1) * NMd : a.M0 + (size_t)b * NMd;
+#pragma unroll
+        for (int q = 0; q < MAXM; ++q) {
+            const int idx = tid + q * T;
+            pM[q] = (idx < NMd) ? Mp[idx] : 0.f;
+            pMt[q] = (wf && idx < NMd) ? a.st_M[bt * NMd + idx] : 0.f;
+        }
+        if (hn) {
+            pWp = (t > 0) ? a.st_w[(bt - 1) * HN + tid] : a.w0[(size_t)b * HN + tid];
+            pWt = a.st_w[bt * HN + tid];
+            pWc = a.st_wc[bt * HN + tid];
+            pWv = a.st_wv[bt * HN + tid];
+        }
+        if (tid < PP) {
+            pU = a.st_u[bt * PP + tid];
+            pDl = (tid >= d.P && tid < d.P + d.O) ? a.dlogits[bt * d.O + (tid - d.P)] : 0.f;
+        }
+        if (tid < hid) {
+            pG = reinterpret_cast<const f32x4*>(a.st_gates)[bt * hid + tid];
+            pCt = a.st_c[bt * hid + tid];
+            pCp = (t > 0) ? a.st_c[(bt - 1) * hid + tid] : a.cs0[(size_t)b * 2 * hid + tid];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < MAXM; ++q) {
+            const int idx = tid + q * T;
+            if (idx < NMd) {
+                const int n = idx / Md, m = idx - n * Md;
+                sMp[n * MP + m] = pM[q];
+                if (wf) sMt[n * MP + m] = pMt[q];
+            }
+        }
+        if (hn) { sWp[tid] = pWp; sWt[tid] = pWt; sWc[tid] = pWc; sWv[tid] = pWv; }
+        if (tid < PP) { sU[tid] = pU; sDU[tid] = pDl; }
+        if (tid < hid) { reinterpret_cast<f32x4*>(sGt)[tid] = pG; sCt[tid] = pCt; sCp[tid] = pCp; }
+    };
+
+    // ---- carried gradients start from the (optional) gradient of the final state
+    for (int i = tid; i < NMd; i += T)
+        sdM[(i / Md) * MP + (i % Md)] = a.dM_fin ? a.dM_fin[(size_t)b * NMd + i] : 0.f;
+    for (int i = tid; i < HN; i += T) sdW[i] = a.dw_fin ? a.dw_fin[(size_t)b * HN + i] : 0.f;
+    for (int i = tid; i < a.ldkT; i += T) {
+        float v = 0.f;
+        if (i < RM) v = a.dread_fin ? a.dread_fin[(size_t)b * RM + i] : 0.f;
+        else if (i < K) v = a.dcs_fin ? a.dcs_fin[(size_t)b * 2 * hid + hid + (i - RM)] : 0.f;
+        sdZ[i] = v;
+    }
+    for (int i = tid; i < hid; i += T) sdC[i] = a.dcs_fin ? a.dcs_fin[(size_t)b * 2 * hid + i] : 0.f;
+    prefetch(S - 1);
+    commit();
+    __syncthreads();
+
+    // per-head block reduction of nq values held by the (h, n) owner threads
+    auto red_write = [&](const float (&v)[NQ], int nq, int base) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q < nq) {
+                const float s = wave_sum(hn ? v[q] : 0.f);
+                if (hn && lane == 0) sRed[(hh * NQT + base + q) * NW + wi] = s;
+            }
+        }
+    };
+    auto red_read = [&](int h, int q) -> float {
+        float s = 0.f;
+        for (int w = 0; w < NW; ++w) s += sRed[(h * NQT + q) * NW + w];
+        return s;
+    };
+
+    for (int t = S - 1; t >= 0; --t) {
+        const size_t bt = (size_t)b * S + t;
+        if (t > 0) prefetch(t - 1);
+
+        // ------------------------------------------------ X1: memory-shaped elementwise + column norms + small vectors
+        for (int idx = tid; idx < NMd; idx += T) {
+            const int n = idx / Md, m = idx - n * Md, ai = n * MP + m;
+            float dMt = sdM[ai];
+            float dMr = 0.f;
+            for (int i = 0; i < R; ++i) dMr += sWt[i * N + n] * sdZ[i * Md + m];
+            if (wf) dMt += dMr;
+            float E = 1.f;
+            for (int j = 0; j < Wh; ++j) E *= (1.0f - sWt[(R + j) * N + n] * sU[d.oE + j * Md + m]);
+            sG[ai] = dMt;
+            sdM[ai] = dMt * E + (wf ? 0.f : dMr);
+        }
+        if (tid < nslC * Md) {     // column sum of squares of M_prev (quirk Q1 normaliser)
+            const int m = tid % Md, sl = tid / Md;
+            const int n0 = sl * nperC, n1 = min(N, n0 + nperC);
+            float s = 0.f;
+            for (int n = n0; n < n1; ++n) { const float v = sMp[n * MP + m]; s += v * v; }
+            sPart[sl * Md + m] = s;
+        }
+        if (tid < H) {             // key norms and shift softmax
+            const int h = tid;
+            float ss = 0.f;
+            for (int m = 0; m < Md; ++m) { const float kv = sU[d.oK + h * Md + m]; ss += kv * kv; }
+            sKss[h] = ss;
+            sKinv[h] = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+            float mx = -INFINITY;
+            for (int j = 0; j < SS; ++j) mx = fmaxf(mx, sU[d.oS + h * SS + j]);
+            float sum = 0.f;
+            for (int j = 0; j < SS; ++j) sum += expf(sU[d.oS + h * SS + j] - mx);
+            for (int j = 0; j < SS; ++j) sSw[h * SS + j] = expf(sU[d.oS + h * SS + j] - mx) / sum;
+        }
+        __syncthreads();
+
+        // ------------------------------------------------ X2: d(w_t) for every head; R1 sums
+        float dwt = 0.f, pw = 0.f, wv = 0.f, wt = 0.f, wc = 0.f, wp = 0.f, gam = 1.f, gate = 0.f;
+        float rv[NQ];
+        if (tid < Md) {
+            float s = 0.f;
+            for (int sl = 0; sl < nslC; ++sl) s += sPart[sl * Md + tid];
+            sCss[tid] = s;
+            sCinv[tid] = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+        }
+        if (hn) {
+            const int h = hh, n = nn;
+            float acc = sdW[tid];
+            if (h < R) {
+                const float* Mr = wf ? sMt : sMp;
+                for (int m = 0; m < Md; ++m) acc += sdZ[h * Md + m] * Mr[n * MP + m];
+            } else {
+                const int j = h - R;
+                for (int m = 0; m < Md; ++m) {
+                    float oth = 1.f;
+                    for (int j2 = 0; j2 < Wh; ++j2)
+                        if (j2 != j) oth *= (1.0f - sWt[(R + j2) * N + n] * sU[d.oE + j2 * Md + m]);
+                    const float g = sG[n * MP + m];
+                    const float Tj = g * sMp[n * MP + m] * oth;
+                    acc += -sU[d.oE + j * Md + m] * Tj + sU[d.oA + j * Md + m] * g;
+                }
+            }
+            dwt = acc;
+            wv = sWv[tid]; wt = sWt[tid]; wc = sWc[tid]; wp = sWp[tid];
+            gam = sU[d.oY + h]; gate = sU[d.oG + h];
+            pw = powf(wv, gam);
+            sWg[tid] = gate * wc + (1.0f - gate) * wp;
+            rv[0] = pw; rv[1] = dwt * wt;
+        }
+        red_write(rv, 2, QR1);
+        __syncthreads();
+
+        // ------------------------------------------------ R2: sharpen backward, shift-weight sums
+        float dpw = 0.f, dwv = 0.f;
+        if (tid < H * Md) {        // normalised keys (needed from R4 on)
+            const int h = tid / Md, m = tid - h * Md;
+            const float kh = sU[d.oK + tid] * sKinv[h];
+            sKhat[tid] = kh;
+            sKs[tid] = kh * sCinv[m];
+        }
+        if (hn) {
+            const float den = red_read(hh, QR1) + 1e-3f;
+            const float s2 = red_read(hh, QR1 + 1);
+            dpw = (dwt - s2) / den;
+            dwv = (wv > 0.f) ? dpw * gam * pw / wv : 0.f;
+            sDwv[tid] = dwv;
+            rv[0] = (wv > 0.f) ? dpw * pw * logf(wv) : 0.f;        // d gamma
+            const int start = -((SS + 1) >> 1);
+#pragma unroll
+            for (int j = 0; j < NQ - 1; ++j) {
+                if (j < SS) {
+                    int src = nn + start + j; src = (src % N + N) % N;
+                    rv[1 + j] = dwv * sWg[hh * N + src];            // d shift_j
+                }
+            }
+        }
+        red_write(rv, 1 + SS, QR2);
+        __syncthreads();
+
+        // ------------------------------------------------ R3: shift + gate backward
+        float dwg = 0.f, dwc = 0.f;
+        float Sgam = 0.f, Ssw[NQ - 1];
+        if (hn) {
+            Sgam = red_read(hh, QR2);
+#pragma unroll
+            for (int j = 0; j < NQ - 1; ++j) Ssw[j] = (j < SS) ? red_read(hh, QR2 + 1 + j) : 0.f;
+            const int start = -((SS + 1) >> 1);
+            for (int j = 0; j < SS; ++j) {
+                int src = nn - (start + j); src = (src % N + N) % N;
+                dwg += sSw[hh * SS + j] * sDwv[hh * N + src];
+            }
+            sdW[tid] = (1.0f - gate) * dwg;                         // carried d(w_{t-1})
+            dwc = gate * dwg;
+            rv[0] = dwg * (wc - wp);                                // d g
+            rv[1] = wc * dwc;                                       // softmax backward inner product
+        }
+        red_write(rv, 2, QR3);
+        __syncthreads();
+
+        // ------------------------------------------------ R4: content softmax backward
+        float Sg = 0.f, dv = 0.f;
+        if (hn) {
+            Sg = red_read(hh, QR3);
+            const float Bs = red_read(hh, QR3 + 1);
+            dv = wc * (dwc - Bs);
+            float sim = 0.f;
+            for (int m = 0; m < Md; ++m) sim += sKs[hh * Md + m] * sMp[nn * MP + m];
+            rv[0] = dv * sim;                                       // d beta
+            sDsim[tid] = dv * sU[d.oB + hh];
+        }
+        red_write(rv, 1, QR4);
+        __syncthreads();
+        if (hn && nn == 0) {       // per-head scalar controls -> raw gradients
+            const int h = hh;
+            const float beta = sU[d.oB + h];
+            sDU[d.oB + h] = red_read(h, QR4) * (1.0f - expf(-beta));                 // softplus' = 1 - exp(-softplus)
+            sDU[d.oG + h] = Sg * gate * (1.0f - gate);
+            sDU[d.oY + h] = Sgam * (1.0f - expf(-(gam - 1.0f)));
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < NQ - 1; ++j) if (j < SS) dot += sSw[h * SS + j] * Ssw[j];
+#pragma unroll
+            for (int j = 0; j < NQ - 1; ++j) if (j < SS) sDU[d.oS + h * SS + j] = sSw[h * SS + j] * (Ssw[j] - dot);
+        }
+
+        // ------------------------------------------------ B7: reductions over slots (keys, column norms, erase, add)
+        if (tid < nslP * nout) {
+            const int o = tid % nout, sl = tid / nout;
+            const int n0 = sl * nperP, n1 = min(N, n0 + nperP);
+            float s = 0.f;
+            if (o < H * Md) {                                  // sum_n dsim[h][n] * M_prev[n][m]
+                const int h = o / Md, m = o - h * Md;
+                for (int n = n0; n < n1; ++n) s += sDsim[h * N + n] * sMp[n * MP + m];
+            } else if (o < H * Md + Md) {                      // sum_n dMhat[n][m] * M_prev[n][m]
+                const int m = o - H * Md;
+                for (int n = n0; n < n1; ++n) {
+                    float dmh = 0.f;
+                    for (int h = 0; h < H; ++h) dmh += sDsim[h * N + n] * sKhat[h * Md + m];
+                    s += dmh * sMp[n * MP + m];
+                }
+            } else {
+                const int o2 = o - H * Md - Md;
+                const int which = o2 / (Wh * Md);              // 0: erase, 1: add
+                const int jm = o2 - which * Wh * Md;
+                const int j = jm / Md, m = jm - j * Md;
+                for (int n = n0; n < n1; ++n) {
+                    const float ww = sWt[(R + j) * N + n];
+                    const float g = sG[n * MP + m];
+                    if (which == 0) {
+                        float oth = 1.f;
+                        for (int j2 = 0; j2 < Wh; ++j2)
+                            if (j2 != j) oth *= (1.0f - sWt[(R + j2) * N + n] * sU[d.oE + j2 * Md + m]);
+                        s += -ww * g * sMp[n * MP + m] * oth;
+                    } else {
+                        s += ww * g;
+                    }
+                }
+            }
+            sPart[sl * nout + o] = s;
+        }
+        __syncthreads();
+        if (tid < nout) {
+            float s = 0.f;
+            for (int sl = 0; sl < nslP; ++sl) s += sPart[sl * nout + tid];
+            if (tid < H * Md) {
+                sDkhat[tid] = s * sCinv[tid % Md];
+            } else if (tid < H * Md + Md) {
+                const int m = tid - H * Md;
+                const float ci = sCinv[m];
+                sC2[m] = (sCss[m] > 1e-12f) ? -ci * ci * ci * s : 0.f;   // dM += M * C2 (2 * d css)
+            } else {
+                const int o2 = tid - H * Md - Md;
+                const int which = o2 / (Wh * Md);
+                const int jm = o2 - which * Wh * Md;
+                if (which == 0) { const float e = sU[d.oE + jm]; sDU[d.oE + jm] = s * e * (1.0f - e); }
+                else { const float av = sU[d.oA + jm]; sDU[d.oA + jm] = s * (1.0f - av * av); }
+            }
+        }
+        __syncthreads();
+        if (tid < H * Md) {
+            const int h = tid / Md;
+            float dot = 0.f;
+            for (int m = 0; m < Md; ++m) dot += sDkhat[h * Md + m] * sU[d.oK + h * Md + m];
+            const float ki = sKinv[h];
+            const float ck = (sKss[h] > 1e-12f) ? -ki * ki * ki * dot : 0.f;
+            const float kv = sU[d.oK + tid];
+            const float dk = ki * sDkhat[tid] + kv * ck;
+            sDU[d.oK + tid] = dk * (1.0f - kv * kv);
+        }
+        for (int idx = tid; idx < NMd; idx += T) {
+            const int n = idx / Md, m = idx - n * Md, ai = n * MP + m;
+            float dmh = 0.f;
+            for (int h = 0; h < H; ++h) dmh += sDsim[h * N + n] * sKhat[h * Md + m];
+            sdM[ai] += sCinv[m] * dmh + sMp[ai] * sC2[m];
+        }
+        __syncthreads();
+        if (tid < PP) a.du[bt * PP + tid] = sDU[tid];
+
+        // ------------------------------------------------ B9: dh' = carried dh + dU . Wa^T
+        if (tid < nslH * hg4) {
+            const int cg = tid % hg4, sl = tid / hg4;
+            const int c0 = sl * nperH, c1 = min(PP, c0 + nperH);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.WaT) + (size_t)c0 * hg4 + cg;
+#pragma unroll 4
+            for (int c = c0; c < c1; ++c, wp4 += hg4) acc += sDU[c] * (*wp4);
+            sPart4[sl * hg4 + cg] = acc;
+        }
+        __syncthreads();
+        // ------------------------------------------------ B10: LSTM cell backward
+        if (tid < hid) {
+            float dh = sdZ[RM + tid];
+            for (int sl = 0; sl < nslH; ++sl) dh += sPart[sl * a.ldhT + tid];
+            const f32x4 g = reinterpret_cast<const f32x4*>(sGt)[tid];
+            const float gi = g[0], gj = g[1], gf = g[2], go = g[3];
+            const float tc = tanhf(sCt[tid]);
+            const float dct = sdC[tid] + dh * go * (1.0f - tc * tc);
+            f32x4 dg;
+            dg[0] = dct * gj * gi * (1.0f - gi);
+            dg[1] = dct * gi * (1.0f - gj * gj);
+            dg[2] = dct * sCp[tid] * gf * (1.0f - gf);
+            dg[3] = dh * tc * go * (1.0f - go);
+            sdC[tid] = dct * gf;
+            reinterpret_cast<f32x4*>(sDG)[tid] = dg;
+            reinterpret_cast<f32x4*>(a.dgates)[bt * hid + tid] = dg;
+        }
+        __syncthreads();
+        // ------------------------------------------------ B11: d[read_prev; h_prev] = dgates . Wr^T
+        if (tid < nslZ * kg4) {
+            const int cg = tid % kg4, sl = tid / kg4;
+            const int r0 = sl * nperZ, r1 = min(4 * hid, r0 + nperZ);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.WrT) + (size_t)r0 * kg4 + cg;
+#pragma unroll 8
+            for (int r = r0; r < r1; ++r, wp4 += kg4) acc += sDG[r] * (*wp4);
+            sPart4[sl * kg4 + cg] = acc;
+        }
+        __syncthreads();
+        if (tid < K) {
+            float s = 0.f;
+            for (int sl = 0; sl < nslZ; ++sl) s += sPart[sl * a.ldkT + tid];
+            sdZ[tid] = s;
+        }
+        if (t > 0) commit();       // next (earlier) step's records: every reader of the old ones has passed a barrier
+        __syncthreads();
+    }
+
+    // ---- gradient of the initial state
+    for (int i = tid; i < NMd; i += T) a.dM0[(size_t)b * NMd + i] = sdM[(i / Md) * MP + (i % Md)];
+    for (int i = tid; i < HN; i += T) a.dw0[(size_t)b * HN + i] = sdW[i];
+    for (int i = tid; i < RM; i += T) a.dread0[(size_t)b * RM + i] = sdZ[i];
+    for (int i = tid; i < hid; i += T) {
+        a.dcs0[(size_t)b * 2 * hid + i] = sdC[i];
+        a.dcs0[(size_t)b * 2 * hid + hid + i] = sdZ[RM + i];
+    }
+}
+
+int ntm_validate_dims(const NtmDims& d, const char* who);
+
+// [rows][cols] -> [cols][ldo] (zero padded), used for WrT / WaT once per optimiser step
+__global__ void transpose_pad_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
+                                     int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < cols && r < ldo) out[(size_t)c * ldo + r] = (r < rows) ? tile[threadIdx.x][i] : 0.f;
+    }
+}
+
+extern "C" int ntk_transpose_pad(const float* in, int ldi, float* out, int ldo, int rows, int cols, void* stream) {
+    NTK_REQUIRE(in && out, NTK_ERR_BAD_PTR, "ntk_transpose_pad: null pointer");
+    NTK_REQUIRE(rows > 0 && cols > 0 && ldi >= cols && ldo >= rows, NTK_ERR_BAD_SHAPE,
+                "ntk_transpose_pad: rows=%d cols=%d ldi=%d ldo=%d", rows, cols, ldi, ldo);
+    dim3 grid((cols + 31) / 32, (ldo + 31) / 32), block(32, 8);
+    transpose_pad_kernel<<<grid, block, 0, (hipStream_t)stream>>>(in, ldi, out, ldo, rows, cols);
+    NTK_CHECK_LAUNCH("ntk_transpose_pad");
+    return NTK_OK;
+}
+
+extern "C" int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int hid, int shift_range, int O,
+                               int write_first,
+                               const float* WrT, int ldkT, const float* WaT, int ldhT,
+                               const float* M0, const float* w0, const float* cs0,
+                               const float* st_gates, const float* st_c, const float* st_u,
+                               const float* st_wc, const float* st_wv, const float* st_w, const float* st_M,
+                               const float* dlogits,
+                               const float* dM_fin, const float* dw_fin, const float* dread_fin, const float* dcs_fin,
+                               float* dgates, float* du, float* dM0, float* dw0, float* dread0, float* dcs0,
+                               void* stream) {
+    NtmBwdArgs a;
+    ntm_fill_dims(a.d, B, S, N, Md, R, Wh, hid, shift_range, O, write_first);
+    int rc = ntm_validate_dims(a.d, "ntk_ntm_seq_bwd");
+    if (rc != NTK_OK) return rc;
+    NTK_REQUIRE(WrT && WaT && M0 && w0 && cs0 && st_gates && st_c && st_u && st_wc && st_wv && st_w && st_M &&
+                    dlogits && dgates && du && dM0 && dw0 && dread0 && dcs0,
+                NTK_ERR_BAD_PTR, "ntk_ntm_seq_bwd: null pointer");
+    NTK_REQUIRE(ntk_aligned16(WrT) && ntk_aligned16(WaT) && ntk_aligned16(st_gates) && ntk_aligned16(dgates),
+                NTK_ERR_BAD_PTR, "ntk_ntm_seq_bwd: WrT/WaT/st_gates/dgates must be 16-byte aligned");
+    NTK_REQUIRE((hid % 4) == 0, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_bwd: hidden=%d must be a multiple of 4", hid);
+    NTK_REQUIRE(ldkT >= a.d.K && (ldkT % 4) == 0 && ldhT >= hid && (ldhT % 4) == 0, NTK_ERR_BAD_SHAPE,
+                "ntk_ntm_seq_bwd: ldkT=%d (K=%d) ldhT=%d (hid=%d)", ldkT, a.d.K, ldhT, hid);
+    NTK_REQUIRE(a.d.SS + 1 <= NQ, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_bwd: shift_range=%d too wide", shift_range);
+    int T = a.d.H * a.d.N;
+    T = ntm_imax(T, 3 * hid);
+    T = ntm_imax(T, a.d.PP);
+    T = ntm_imax(T, a.d.K);
+    T = ((T + 63) / 64) * 64;
+    T = ntm_imax(T, a.d.H * a.d.Md + a.d.Md + 2 * a.d.Wh * a.d.Md);
+    T = ((T + 63) / 64) * 64;
+    NTK_REQUIRE(T <= 1024 && a.d.H * a.d.N <= 1024 && a.d.N * a.d.Md <= MAXM * T, NTK_ERR_UNSUPPORTED,
+                "ntk_ntm_seq_bwd: heads*mem_size=%d (max 1024) / mem_size*mem_dim=%d exceed one workgroup",
+                a.d.H * a.d.N, a.d.N * a.d.Md);
+    a.WrT = WrT; a.WaT = WaT; a.ldkT = ldkT; a.ldhT = ldhT; a.M0 = M0; a.w0 = w0; a.cs0 = cs0;
+    a.st_gates = st_gates; a.st_c = st_c; a.st_u = st_u; a.st_wc = st_wc; a.st_wv = st_wv; a.st_w = st_w; a.st_M = st_M;
+    a.dlogits = dlogits; a.dM_fin = dM_fin; a.dw_fin = dw_fin; a.dread_fin = dread_fin; a.dcs_fin = dcs_fin;
+    a.dgates = dgates; a.du = du; a.dM0 = dM0; a.dw0 = dw0; a.dread0 = dread0; a.dcs0 = dcs0;
+    NtmBwdLds L;
+    ntm_bwd_lds(a.d, T, ldkT, ldhT, L);
+    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_bwd: needs %zu B of LDS (> 160 KiB)", lds_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ntk_set_error("ntk_ntm_seq_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
+        attr_set = true;
+    }
+    if (T <= 768) ntm_seq_bwd_kernel<768><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else ntm_seq_bwd_kernel<1024><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    NTK_CHECK_LAUNCH("ntk_ntm_seq_bwd");
+    return NTK_OK;
+}

@@ -71,7 +71,8 @@ static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
     L.total = o;
 }
 
-__global__ __launch_bounds__(1024) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds L) {
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const NtmDims& d = a.d;
     const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
@@ -410,11 +411,14 @@ extern "C" int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int h
                 "ntk_ntm_seq_fwd: state needs %zu B of LDS (> 160 KiB)", lds_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { ntk_set_error("ntk_ntm_seq_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
         attr_set = true;
     }
-    ntm_seq_fwd_kernel<<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    if (T <= 768) ntm_seq_fwd_kernel<768><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else ntm_seq_fwd_kernel<1024><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     NTK_CHECK_LAUNCH("ntk_ntm_seq_fwd");
     return NTK_OK;
 }

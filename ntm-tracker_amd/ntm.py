@@ -144,6 +144,9 @@ def gemm_nt(A, B, bias=None, out=None):
     return out
 
 
+_WS = {}   # per-device split-K slab workspace, grown to the largest request
+
+
 def gemm_tn(A, B, out, accumulate=False, splits=None, workspace=None):
     """out[M,N] (+)= A[K,M]^T @ B[K,N] on the fp32 MFMA kernel (fixed-order split-K)."""
     K, M = A.shape
@@ -155,7 +158,10 @@ def gemm_tn(A, B, out, accumulate=False, splits=None, workspace=None):
     L = _lib.lib()
     need = L.ntk_gemm_tn_workspace_bytes(M, N, splits) // 4
     if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(need, device=A.device, dtype=torch.float32)
+        workspace = _WS.get(A.device)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, device=A.device, dtype=torch.float32)
+            _WS[A.device] = workspace
     _lib.check(L.ntk_gemm_tn_f32(_P(A), A.stride(0), _P(B), B.stride(0), _P(out), out.stride(0), M, N, K, splits,
                                  1 if accumulate else 0, _P(workspace), _lib.stream()), "ntk_gemm_tn_f32")
     return out
@@ -279,6 +285,47 @@ class NTMCell(object):
             _lib.stream()), "ntk_ntm_seq_fwd")
         rec["xproj"] = xproj
         return logits, outputs, new, rec
+
+    def backward_sequence(self, X, state0, rec, dlogits, dfinal=None, workspace=None):
+        """BPTT through a recorded sequence: fills ``self.params.grad`` (kernel layout) with
+        d loss / d params given ``dlogits`` [B,S,O] (and optionally gradients w.r.t. the final
+        state).  Returns the gradient w.r.t. the initial state tensors."""
+        d, dev, L = self.dims, self.device, _lib.lib()
+        B, S, _ = X.shape
+        P = self.params
+        ldkT, ldhT = (d.K + 3) // 4 * 4, (d.hid + 3) // 4 * 4
+        WrT = torch.empty((4 * d.hid, ldkT), device=dev)
+        WaT = torch.empty((d.PP, ldhT), device=dev)
+        st = _lib.stream()
+        _lib.check(L.ntk_transpose_pad(_P(P.view("Wr")), 4 * d.hid, _P(WrT), ldkT, d.K, 4 * d.hid, st), "ntk_transpose_pad")
+        _lib.check(L.ntk_transpose_pad(_P(P.view("Wa")), d.PP, _P(WaT), ldhT, d.hid, d.PP, st), "ntk_transpose_pad")
+        dgates = torch.empty((B, S, 4 * d.hid), device=dev)
+        du = torch.empty((B, S, d.PP), device=dev)
+        g0 = self.state_placeholder(B)
+        df = dfinal or {}
+        _lib.check(L.ntk_ntm_seq_bwd(
+            B, S, d.N, d.Md, d.R, d.Wh, d.hid, d.shift_range, d.O, 1 if self.write_first else 0,
+            _P(WrT), ldkT, _P(WaT), ldhT,
+            _P(state0["M"].contiguous()), _P(state0["w"].contiguous()), _P(state0["controller_state"].contiguous()),
+            _P(rec["gates"]), _P(rec["c"]), _P(rec["u"]), _P(rec["wc"]), _P(rec["wv"]), _P(rec["w"]), _P(rec["M"]),
+            _P(dlogits.contiguous()),
+            _np(df.get("M")), _np(df.get("w")), _np(df.get("read")), _np(df.get("controller_state")),
+            _P(dgates), _P(du), _P(g0["M"]), _P(g0["w"]), _P(g0["read"]), _P(g0["controller_state"]), st),
+            "ntk_ntm_seq_bwd")
+        BS = B * S
+        # weight gradients: three k-major contractions over all B*S recorded rows
+        gemm_tn(dgates.view(BS, 4 * d.hid), X.view(BS, d.ldx), P.view("WxT", grad=True), workspace=workspace)
+        gemm_tn(rec["z"].view(BS, d.ldz), dgates.view(BS, 4 * d.hid), P.view("Wr", grad=True), workspace=workspace)
+        gemm_tn(rec["h"].view(BS, d.ldh), du.view(BS, d.PP), P.view("Wa", grad=True), workspace=workspace)
+        return g0
+
+    def init_state_backward(self, g0, batch_size):
+        """Gradient of the trainable initial state (ntm_cell.py:292-306): summed over the batch."""
+        L = _lib.lib()
+        for name, key, act in (("V_M", "M", 0), ("V_w", "w", 1), ("V_r", "read", 0)):
+            v = self.params.view(name)
+            _lib.check(L.ntk_ntm_init_state_bwd(_P(v), _P(g0[key]), _P(self.params.view(name, grad=True)),
+                                                v.numel(), batch_size, act, 0, _lib.stream()), "ntk_ntm_init_state_bwd")
 
     # ---- the reference step() API
     def __call__(self, inputs, prev_state, M_prev=None, w_prev=None, read_prev=None,

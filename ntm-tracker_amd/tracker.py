@@ -1,0 +1,126 @@
+"""Graph assembly of the offsets tracker (ntm_offsets(), direct_offset_output.py:401-653)
+on the HIP path: frames -> VGG conv4_3 -> 64-point gather + serialise -> NTM
+sequence -> output gather / tanh / l2 loss -> BPTT -> clip + RMSProp.
+
+One process drives one GPU; with ``torch.distributed`` initialised the flat
+gradient bucket is summed across ranks (one RCCL all-reduce per step) before
+the clip, so every rank applies the identical update -- the same result as a
+single process running the global batch, because the loss is an un-normalised
+sum (direct_offset_output.py:606).
+"""
+import torch
+
+from . import _lib
+from .ntm import NTMCell, _P, _np
+from .vgg import VGG16Conv43
+
+# receptive_field_sizes.py:135-143: y, x in {6, 8, ..., 20} on the 28x28 conv4_3 map
+GRID_START, GRID_STEP, GRID_N = 6, 2, 8
+NUM_FEATURES = GRID_N * GRID_N
+
+
+def gather_serialize(fmap, gts0, B, T, ldx, out=None):
+    """fmap [B*T,Hf,Wf,C] conv4_3 features, gts0 [B,64] frame-0 heat-map (or None)
+    -> X [B, T*65, ldx] (direct_offset_output.py:392-399, :439-500)."""
+    F, Hf, Wf, C = fmap.shape
+    assert F == B * T
+    S = T * (NUM_FEATURES + 1)
+    if out is None:
+        out = torch.empty((B, S, ldx), device=fmap.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ntk_gather_serialize(_P(fmap), _np(gts0), _P(out), B, T, Hf, Wf, C, ldx,
+                                              GRID_START, GRID_STEP, GRID_N, _lib.stream()), "ntk_gather_serialize")
+    return out
+
+
+def offset_loss(logits, offsets, T, want_grad=True):
+    """direct_offset_output.py:581-606.  Returns (loss[1], pred[B,T-1,O], dlogits or None)."""
+    B, S, O = logits.shape
+    pred = torch.empty((B, T - 1, O), device=logits.device)
+    loss = torch.empty(1, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _lib.check(_lib.lib().ntk_offset_loss(_P(logits), _P(offsets.contiguous()), _P(pred), _P(loss), _np(dlogits),
+                                         B, T, NUM_FEATURES, O, _lib.stream()), "ntk_offset_loss")
+    return loss, pred, dlogits
+
+
+class RMSPropClip(object):
+    """tf.clip_by_global_norm + tf.train.RMSPropOptimizer on one flat buffer
+    (direct_offset_output.py:620-626): ms slot starts at 1, epsilon inside the sqrt."""
+
+    def __init__(self, params, learning_rate=1e-4, decay=0.95, momentum=0.9, epsilon=1e-10, max_gradient_norm=5.0):
+        self.p = params
+        self.lr, self.decay, self.momentum, self.eps, self.clip = learning_rate, decay, momentum, epsilon, max_gradient_norm
+        self.ms = torch.ones_like(params.flat)
+        self.mom = torch.zeros_like(params.flat)
+        L = _lib.lib()
+        self.ws = torch.empty(max(1, L.ntk_global_norm_workspace_bytes(params.numel) // 4), device=params.flat.device)
+        self.gnorm = torch.zeros(1, device=params.flat.device)
+        self.global_step = 0
+
+    def step(self):
+        L, st = _lib.lib(), _lib.stream()
+        n = self.p.numel
+        _lib.check(L.ntk_global_norm(_P(self.p.grad), n, _P(self.ws), _P(self.gnorm), st), "ntk_global_norm")
+        _lib.check(L.ntk_rmsprop_clip_step(_P(self.p.flat), _P(self.p.grad), _P(self.ms), _P(self.mom), n,
+                                           self.lr, self.decay, self.momentum, self.eps, self.clip, _P(self.gnorm), st),
+                   "ntk_rmsprop_clip_step")
+        self.global_step += 1
+
+
+class NTMOffsetTracker(object):
+    """VGG-16 conv4_3 + NTMCell offsets tracker, defaults from direct_offset_output.py:21-42."""
+
+    def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
+                 num_layers=1, read_head_size=4, write_head_size=1, write_first=False, init_scale=0.05,
+                 learning_rate=1e-4, decay=0.95, momentum=0.9, max_gradient_norm=5.0, feature_channels=512,
+                 device="cuda", seed=42, vgg_chunk_frames=64):
+        self.B, self.T = int(batch_size), int(sequence_length)
+        self.S = self.T * (NUM_FEATURES + 1)
+        self.device = torch.device(device)
+        self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames) if vgg_weights else None
+        self.cell = NTMCell(2, mem_size=mem_size, mem_dim=mem_dim, controller_hidden_size=hidden_size,
+                            controller_num_layers=num_layers, write_head_size=write_head_size,
+                            read_head_size=read_head_size, write_first=write_first,
+                            input_dim=feature_channels + 2, device=self.device, init_scale=init_scale, seed=seed)
+        self.opt = RMSPropClip(self.cell.params, learning_rate, decay, momentum, 1e-10, max_gradient_norm)
+
+    # ---- forward pieces
+    def features(self, frames):
+        if self.vgg is None:
+            raise _lib.NtkError("tracker was built without VGG weights")
+        return self.vgg(frames)
+
+    def serialize(self, fmap, gts0):
+        return gather_serialize(fmap, gts0, self.B, self.T, self.cell.dims.ldx)
+
+    def forward_features(self, fmap, gts0, record=False):
+        X = self.serialize(fmap, gts0)
+        st0 = self.cell.zero_state(self.B)
+        logits, _outs, new, rec = self.cell.run_sequence(X, st0, record=record, want_outputs=False)
+        return X, st0, logits, rec
+
+    def infer(self, frames, gts0):
+        """-> predicted offsets [B,T-1,2] (tanh of the logits at each frame's delimiter step)."""
+        _X, _st0, logits, _ = self.forward_features(self.features(frames), gts0)
+        offs = torch.zeros((self.B, self.T, 2), device=self.device)
+        _loss, pred, _ = offset_loss(logits, offs, self.T, want_grad=False)
+        return pred
+
+    # ---- one optimiser step
+    def loss_and_grads(self, fmap, gts0, offsets):
+        X, st0, logits, rec = self.forward_features(fmap, gts0, record=True)
+        loss, pred, dlogits = offset_loss(logits, offsets, self.T)
+        g0 = self.cell.backward_sequence(X, st0, rec, dlogits)
+        self.cell.init_state_backward(g0, self.B)
+        return loss, pred
+
+    def train_step(self, frames, gts0, offsets):
+        """VGG forward, NTM forward + BPTT, gradient all-reduce (if distributed), clip + RMSProp.
+        Returns the (local) loss as a 1-element device tensor."""
+        fmap = self.features(frames)
+        loss, _pred = self.loss_and_grads(fmap, gts0, offsets)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(self.cell.params.grad, op=torch.distributed.ReduceOp.SUM)
+        self.opt.step()
+        return loss

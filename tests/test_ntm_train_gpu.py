@@ -1,0 +1,134 @@
+"""GPU parity of the training path: serialiser, loss, BPTT gradients, clip + RMSProp
+against the numpy / torch-autograd oracles."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ntm_oracle as O
+from oracle import ntm_oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def test_gather_serialize_matches_oracle(cuda):
+    from ntmtrack import tracker
+    rng = np.random.default_rng(1)
+    B, T, C = 2, 3, 512
+    fmap = rng.standard_normal((B * T, 28, 28, C)).astype(np.float32)
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    ref = O.serialize_inputs(O.extract_features(fmap).reshape(B, T, 64, C), gts)
+    X = tracker.gather_serialize(torch.from_numpy(fmap).to(cuda), torch.from_numpy(gts[:, 0].copy()).to(cuda), B, T, 516)
+    torch.cuda.synchronize()
+    got = X.cpu().numpy()
+    assert got.shape == (B, T * 65, 516)
+    assert np.array_equal(got[:, :, :514], ref)          # pure copies: bit exact
+    assert np.all(got[:, :, 514:] == 0)
+
+
+def test_offset_loss_matches_oracle(cuda):
+    from ntmtrack import tracker
+    rng = np.random.default_rng(2)
+    B, T = 3, 5
+    logits = rng.standard_normal((B, T * 65, 2)).astype(np.float32)
+    offs = rng.uniform(-0.5, 0.5, size=(B, T, 2)).astype(np.float32)
+    loss_ref, pred_ref = O.offset_loss(logits.astype(np.float64), offs.astype(np.float64))
+    loss, pred, dlog = tracker.offset_loss(torch.from_numpy(logits).to(cuda), torch.from_numpy(offs).to(cuda), T)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-5)
+    np.testing.assert_allclose(pred.cpu().numpy(), pred_ref, atol=1e-6)
+    lt = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    l2, _ = OT.offset_loss(lt, torch.tensor(offs, dtype=torch.float64))
+    l2.backward()
+    np.testing.assert_allclose(dlog.cpu().numpy(), lt.grad.numpy(), atol=1e-6)
+
+
+GRAD_CASES = [
+    ("c2_shape_T3", dict(mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=200, controller_num_layers=1,
+                         write_head_size=1, read_head_size=4), 514, 3, 2, 0.05),
+    ("r1w1_T2", dict(mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=100, controller_num_layers=1,
+                     write_head_size=1, read_head_size=1), 514, 2, 2, 0.1),
+    ("write_first_2w", dict(mem_size=64, mem_dim=8, shift_range=1, controller_hidden_size=64, controller_num_layers=1,
+                            write_head_size=2, read_head_size=2, write_first=True), 514, 2, 3, 0.2),
+]
+
+
+@pytest.mark.parametrize("name,kw,D,T,B,scale", GRAD_CASES, ids=[c[0] for c in GRAD_CASES])
+def test_bptt_gradients_match_autograd_oracle(cuda, name, kw, D, T, B, scale):
+    from ntmtrack.ntm import NTMCell
+    from ntmtrack import tracker
+    cfg = O.NTMConfig(D, 2, **kw)
+    rng = np.random.default_rng(21)
+    params = O.init_params(cfg, rng, scale=scale)
+    for k in params:
+        if k.endswith("biases"):
+            params[k] = rng.uniform(-scale, scale, size=params[k].shape).astype(np.float32)
+    S = T * 65
+    # serialised inputs of the tracking task: sparse relu-like features + delimiter/target columns
+    feats = np.maximum(rng.standard_normal((B, T, 64, 512)), 0).astype(np.float32)
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    x = O.serialize_inputs(feats, gts)
+    offs = rng.uniform(-0.5, 0.5, size=(B, T, 2)).astype(np.float32)
+    loss_ref, grads_ref, logits_ref, _ = OT.loss_and_grads(cfg, params, x, offs)
+
+    cell = NTMCell(2, mem_size=cfg.mem_size, mem_dim=cfg.mem_dim, shift_range=cfg.shift_range,
+                   controller_hidden_size=cfg.hidden, controller_num_layers=1, write_head_size=cfg.write_heads,
+                   read_head_size=cfg.read_heads, write_first=cfg.write_first, device=cuda)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, input_dim=D)
+    X = cell._pad_inputs(torch.from_numpy(x).to(cuda))
+    st0 = cell.zero_state(B)
+    logits, _o, _new, rec = cell.run_sequence(X, st0, record=True)
+    loss, pred, dlogits = tracker.offset_loss(logits, torch.from_numpy(offs).to(cuda), T)
+    g0 = cell.backward_sequence(X, st0, rec, dlogits)
+    cell.init_state_backward(g0, B)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logits.cpu().numpy(), logits_ref, atol=2e-5)
+    np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-4)
+    got = cell.params.to_tf(grad=True)
+    for k in sorted(grads_ref):
+        err = _relerr(got[k].numpy(), grads_ref[k])
+        assert err < 2e-3, "%s: relative error %.3e" % (k, err)
+
+
+def test_train_step_matches_oracle_update(cuda):
+    """One full optimiser step (no VGG): clip_by_global_norm(5) + TF RMSProp on the packed buffer
+    equals the oracle update applied to the autograd gradients."""
+    from ntmtrack import tracker
+    name, kw, D, T, B, scale = GRAD_CASES[0]
+    cfg = O.NTMConfig(D, 2, **kw)
+    rng = np.random.default_rng(33)
+    params = O.init_params(cfg, rng, scale=0.3)       # large weights -> gradient norm above the clip
+    feats = np.maximum(rng.standard_normal((B, T, 64, 512)), 0).astype(np.float32) * 3
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    offs = rng.uniform(-0.5, 0.5, size=(B, T, 2)).astype(np.float32)
+    x = O.serialize_inputs(feats, gts)
+    loss_ref, grads_ref, _, _ = OT.loss_and_grads(cfg, params, x, offs)
+    names = sorted(grads_ref)
+    clipped, gn = O.clip_by_global_norm([grads_ref[k] for k in names], 5.0)
+    new_ref = {}
+    for k, g in zip(names, clipped):
+        pnew, _, _ = O.rmsprop_step(params[k].astype(np.float64), g, np.ones_like(g), np.zeros_like(g))
+        new_ref[k] = pnew
+
+    trk = tracker.NTMOffsetTracker(B, T, vgg_weights=None, device=cuda)
+    trk.cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, input_dim=D)
+    trk.opt = tracker.RMSPropClip(trk.cell.params)
+    # feed the features through a fake conv4_3 map so the gather kernel is on the path too
+    fmap = np.zeros((B * T, 28, 28, 512), np.float32)
+    for i, (y, xx) in enumerate(O.CONV43_POINTS):
+        fmap[:, y, xx, :] = feats.reshape(B * T, 64, 512)[:, i]
+    loss, _ = trk.loss_and_grads(torch.from_numpy(fmap).to(cuda), torch.from_numpy(gts[:, 0].copy()).to(cuda),
+                                 torch.from_numpy(offs).to(cuda))
+    trk.opt.step()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(trk.opt.gnorm.cpu()), gn, rtol=2e-3)
+    assert gn > 5.0
+    got = trk.cell.state_dict()
+    for k in names:
+        delta_ref = new_ref[k] - params[k]
+        err = np.max(np.abs(got[k].numpy().astype(np.float64) - new_ref[k]))
+        # fp32 storage of the parameter (|p| <= 0.3 -> half an ulp = 1.5e-8) plus 0.5 % of the step
+        assert err <= 3e-8 + 5e-3 * np.max(np.abs(delta_ref)), "%s: %.3e (step %.3e)" % (k, err, np.max(np.abs(delta_ref)))
