@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the VGG16 + NTM(128x20) offsets tracker training step.
+
+Contract (see the task statement):  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+one rank per GPU over RCCL.  Rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
+VGG-16 conv1_1..conv4_3 on B*T frames -> 64-point gather + serialise -> NTM forward
+(T*65 steps) -> offsets loss -> BPTT -> gradient all-reduce (N > 1) -> clip + RMSProp.
+Workload = BASELINE.json configs[1]: batch 32 sequences / GPU, seq_len 20, 224x224 frames,
+NTMCell(128x20, hidden 200, 4 read / 1 write heads), fp32 (weak scaling: per-GPU work fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def log(msg):
+    print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
+def synth_inputs(B, T, device, seed):
+    """SURVEY 8(d) synthetic inputs: frames U[0,255) - VGG_MEAN; frame-0 heat-map =
+    discrete_gauss((.5,.5),(8,8),1); offsets U(-.5,.5), frame 0 = 0."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mean = torch.tensor([123.68, 116.78, 103.94])
+    frames = torch.empty((B * T, 224, 224, 3), dtype=torch.float32)
+    for i in range(0, B * T, 64):
+        n = min(64, B * T - i)
+        frames[i:i + n] = torch.rand((n, 224, 224, 3), generator=g) * 255.0 - mean
+    y, x = np.ogrid[-3.5:4.5, -3.5:4.5]
+    hm = np.exp(-(x * x + y * y) / 2.0)
+    hm[hm < np.finfo(hm.dtype).eps * hm.max()] = 0
+    hm /= hm.sum()
+    gts0 = torch.from_numpy(np.tile(hm.reshape(1, 64), (B, 1)).astype(np.float32))
+    offs = torch.rand((B, T, 2), generator=g) - 0.5
+    offs[:, 0, :] = 0
+    return frames.to(device), gts0.to(device), offs.to(device)
+
+
+def vgg_weights(seed):
+    rng = np.random.default_rng(seed)
+    from ntmtrack.vgg import VGG_LAYERS
+    ws = {}
+    for name, cin, cout, _ in VGG_LAYERS:
+        ws[name] = ((rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32),
+                    np.zeros(cout, np.float32))
+    return ws
+
+
+def cpu_baseline(ws, n_vgg_frames=4, T=20):
+    """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded
+    sample: VGG trunk on `n_vgg_frames` frames (torch-CPU conv2d, the op granularity TF-CPU would
+    run) + NTM forward + BPTT of ONE sequence of T frames (torch-CPU autograd restatement),
+    combined as frames/s of one sequence: T / (T * t_vgg_per_frame + t_ntm_per_sequence)."""
+    from oracle import ntm_oracle as O
+    from oracle import ntm_oracle_torch as OT
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the box's CPU share for one GPU is 16 cores
+    torch.set_num_threads(cores)
+    log("cpu_baseline: %d threads" % cores)
+    rng = np.random.default_rng(42)
+    frames = (rng.uniform(0, 255, size=(n_vgg_frames, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)
+    OT.vgg16_conv43(frames[:1], ws)            # warm the conv primitives
+    t0 = time.perf_counter()
+    fm = OT.vgg16_conv43(frames, ws)
+    t_vgg = (time.perf_counter() - t0) / n_vgg_frames
+    log("cpu_baseline: VGG %.3f s/frame" % t_vgg)
+    cfg = O.NTMConfig(514, 2, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=200,
+                      controller_num_layers=1, write_head_size=1, read_head_size=4)
+    params = O.init_params(cfg, rng)
+    feats = np.maximum(rng.standard_normal((1, T, 64, 512)), 0).astype(np.float32)
+    x = O.serialize_inputs(feats, rng.uniform(0, 1, size=(1, T, 64)).astype(np.float32))
+    offs = rng.uniform(-.5, .5, size=(1, T, 2)).astype(np.float32)
+    t0 = time.perf_counter()
+    OT.loss_and_grads(cfg, params, x, offs, dtype=torch.float32)
+    t_ntm = time.perf_counter() - t0
+    log("cpu_baseline: NTM fwd+bwd %.2f s/sequence" % t_ntm)
+    fps = T / (T * t_vgg + t_ntm)
+    return {"value": round(fps, 3), "unit": "frames/sec", "cores": cores, "kind": "port",
+            "sample": "VGG conv1_1..conv4_3 on %d frames (torch-CPU conv2d, %.3f s/frame) + NTM fwd+BPTT of 1 "
+                      "sequence x %d frames (torch-CPU autograd restatement, %.2f s); frames/s of one sequence"
+                      % (n_vgg_frames, t_vgg, T, t_ntm)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
+    ap.add_argument("--seq-len", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print("bench.py: --gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world),
+              file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ntmtrack import tracker
+    from ntmtrack.vgg import conv_flops_per_frame
+
+    B, T = args.batch, args.seq_len
+    ws = vgg_weights(42)
+    trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42)   # same init on every rank
+    log("tracker built; generating synthetic inputs")
+    frames, gts0, offs = synth_inputs(B, T, dev, 42 + rank)
+    log("inputs resident in HBM: frames %s" % (tuple(frames.shape),))
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    marks = []
+
+    def one_step(timed):
+        if timed:
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+        fmap = trk.features(frames)
+        if timed:
+            e1.record()
+        if args.mode == "train":
+            trk.loss_and_grads(fmap, gts0, offs)
+            if dist is not None:
+                dist.all_reduce(trk.cell.params.grad, op=dist.ReduceOp.SUM)
+            trk.opt.step()
+        else:
+            trk.forward_features(fmap, gts0)
+        if timed:
+            e2.record()
+            marks.append((e0, e1, e2))
+
+    for i in range(args.warmup):
+        one_step(False)
+        torch.cuda.synchronize()
+        log("warmup step %d done" % i)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log("timed %d steps in %.3f s" % (args.steps, elapsed))
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames_total = world * B * T * args.steps
+        vgg_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in marks]))
+        ntm_ms = float(np.mean([b.elapsed_time(c) for _, b, c in marks]))
+        flops = conv_flops_per_frame() * B * T
+        achieved = flops / (vgg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "frames/sec (whole node) VGG16+NTM(128x20) seq_len=%d" % T,
+            "value": round(frames_total / elapsed, 2), "unit": "frames/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: VGG-16 conv1_1..conv4_3 + NTMCell(128x20, hidden 200, R4/W1) "
+                                   "direct_offset_output %s step, batch %d sequences/GPU, seq_len %d, 224x224 frames"
+                                   % ("training" if args.mode == "train" else "inference", B, T),
+                       "global_batch": world * B, "seq_len": T, "steps_per_sequence": T * 65,
+                       "parallelism": "dp%d" % world, "mode": args.mode},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_relu_kernel (VGG trunk, 10 layers)",
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "algorithmic_flops_per_frame": conv_flops_per_frame()},
+            "breakdown_ms": {"vgg_trunk": round(vgg_ms, 3), "ntm_fwd_bwd_opt": round(ntm_ms, 3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ws)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

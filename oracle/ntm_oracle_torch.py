@@ -138,3 +138,21 @@ def loss_and_grads(cfg, params_np, inputs_np, offsets_np, num_features=64, dtype
     loss, pred = offset_loss(logits, off, num_features)
     loss.backward()
     return float(loss.detach()), {k: v.grad.numpy() for k, v in p.items()}, logits.detach().numpy(), pred.detach().numpy()
+
+
+def vgg16_conv43(frames, weights):
+    """VGG conv1_1..conv4_3 on torch-CPU ops (conv2d SAME + bias + ReLU, 2x2/2 max-pool):
+    the op granularity TF-CPU would execute for the frozen graph
+    (direct_offset_output.py:417-422, vgg.py:155-161).  frames [F,H,W,3] NHWC,
+    weights {name: (w HWIO, b)} numpy.  Returns [F,H/8,W/8,512] numpy."""
+    x = torch.as_tensor(frames).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for name, _cin, _cout, pool in O.VGG_LAYERS:
+            w, b = weights[name]
+            wt = torch.as_tensor(w).permute(3, 2, 0, 1).contiguous()      # HWIO -> OIHW
+            x = torch.relu(torch.nn.functional.conv2d(x, wt, torch.as_tensor(b), padding=1))
+            if name == "conv4_3":
+                break
+            if pool:
+                x = torch.nn.functional.max_pool2d(x, 2, 2)
+    return x.permute(0, 2, 3, 1).contiguous().numpy()
