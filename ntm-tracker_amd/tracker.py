@@ -83,6 +83,12 @@ class NTMOffsetTracker(object):
                             read_head_size=read_head_size, write_first=write_first,
                             input_dim=feature_channels + 2, device=self.device, init_scale=init_scale, seed=seed)
         self.opt = RMSPropClip(self.cell.params, learning_rate, decay, momentum, 1e-10, max_gradient_norm)
+        # two-stage software pipeline: the frozen VGG trunk of batch i+1 runs on its own HIP stream
+        # while the NTM forward/BPTT/optimiser of batch i runs on a high-priority stream
+        self._s_vgg = None
+        self._s_ntm = None
+        self._slots = []
+        self._pending = []
 
     # ---- forward pieces
     def features(self, frames):
@@ -113,6 +119,57 @@ class NTMOffsetTracker(object):
         g0 = self.cell.backward_sequence(X, st0, rec, dlogits)
         self.cell.init_state_backward(g0, self.B)
         return loss, pred
+
+    # ---- pipelined training: VGG(i+1) overlaps NTM(i)
+    def _streams(self):
+        if self._s_vgg is None:
+            self._s_vgg = torch.cuda.Stream(device=self.device)
+            self._s_ntm = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._s_vgg, self._s_ntm
+
+    def submit_features(self, frames):
+        """Enqueue the VGG trunk for `frames` on the feature stream (returns immediately).
+        At most two submissions may be outstanding."""
+        s_vgg, _ = self._streams()
+        if len(self._pending) >= 2:
+            raise _lib.NtkError("submit_features: two feature batches already outstanding")
+        F = frames.shape[0]
+        if not self._slots:
+            self._slots = [dict(buf=torch.empty((F, frames.shape[1] // 8, frames.shape[2] // 8, 512), device=self.device),
+                                free=None) for _ in range(2)]
+        busy = [id(p[0]) for p in self._pending]
+        slot = next(sl for sl in self._slots if id(sl) not in busy)
+        s_vgg.wait_stream(torch.cuda.current_stream(self.device))       # frames were produced on the caller's stream
+        if slot["free"] is not None:
+            s_vgg.wait_event(slot["free"])                               # NTM pass that last read this buffer is done
+        with torch.cuda.stream(s_vgg):
+            self.vgg(frames, out=slot["buf"])
+            done = torch.cuda.Event()
+            done.record(s_vgg)
+        self._pending.append((slot, done))
+
+    def train_on_submitted(self, gts0, offsets):
+        """NTM forward + BPTT + (all-reduce) + optimiser on the oldest submitted feature batch."""
+        _, s_ntm = self._streams()
+        slot, done = self._pending.pop(0)
+        s_ntm.wait_stream(torch.cuda.current_stream(self.device))
+        s_ntm.wait_event(done)
+        with torch.cuda.stream(s_ntm):
+            loss, _pred = self.loss_and_grads(slot["buf"], gts0, offsets)
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                    torch.distributed.get_world_size() > 1:
+                torch.distributed.all_reduce(self.cell.params.grad, op=torch.distributed.ReduceOp.SUM)
+            self.opt.step()
+            slot["free"] = torch.cuda.Event()
+            slot["free"].record(s_ntm)
+        return loss
+
+    def join(self):
+        """Make the caller's stream wait for everything enqueued on the pipeline streams."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._s_vgg is not None:
+            cur.wait_stream(self._s_vgg)
+            cur.wait_stream(self._s_ntm)
 
     def train_step(self, frames, gts0, offsets):
         """VGG forward, NTM forward + BPTT, gradient all-reduce (if distributed), clip + RMSProp.
