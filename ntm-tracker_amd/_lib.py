@@ -25,6 +25,7 @@ def _sig(lib):
         "ntk_version": (c_int, []),
         "ntk_last_error": (ctypes.c_char_p, []),
         "ntk_vgg_packed_k": (c_int, [c_int]),
+        "ntk_vgg_set_conv_variant": (c_int, [c_int]),
         "ntk_vgg_pack_weights": (c_int, [P, P, c_int, c_int, P]),
         "ntk_vgg_conv3x3_relu_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
         "ntk_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),

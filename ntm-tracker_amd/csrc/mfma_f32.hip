@@ -6,12 +6,16 @@
 //
 // Tile: 128 x BN x 32 per 256-thread workgroup (4 waves as 2x2, each wave a
 // 64 x BN/2 block of 32x32 MFMA tiles).  Operands are staged global -> VGPR ->
-// LDS (two LDS buffers, one barrier per K-tile); the next K-tile's global
-// loads are in flight while the current tile's 64 MFMAs per wave issue.
-// fp32 MFMA runs at 64 cycles per instruction per SIMD, so one K-tile is
-// ~4096 MFMA cycles per wave against 8 x 16-byte loads per thread: the loop is
-// matrix-pipe bound by construction, and 2 workgroups per CU (launch bounds)
-// cover each other's barriers.
+// LDS; the next K-tile's global loads are in flight while the current tile's
+// 64 MFMAs per wave issue.  fp32 MFMA runs at 64 cycles per instruction per
+// SIMD, so one K-tile is ~4096 MFMA cycles per wave against 8 x 16-byte loads
+// per thread: the loop is matrix-pipe bound by construction.  Measured on
+// MI355X (profiles/): co-resident waves of one SIMD run in lockstep
+// and stall at their barriers together, so occupancy decides the pipe's duty
+// cycle -- the shipped conv variant (2) keeps ONE LDS buffer (two barriers per
+// K-tile, 38 KB) so that 3 workgroups fit a CU: 126-128 TFLOP/s per layer vs
+// 116-118 with two LDS buffers at 2 workgroups/CU (variant 0); static wave
+// priority (1) and 4 workgroups/CU at 128 VGPRs (3, spills) both lose.
 #include "common.h"
 
 namespace {
@@ -50,6 +54,38 @@ __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const fl
 
 // generic double-buffered pipeline.  LA/LB: functors  f32x4 operator()(int slot, int kt)
 // slot = which of the thread's rows (A: 4 rows, B: BN/32 rows); LDS row = (tid>>3) + 32*slot, k-group = tid&7
+template <int BN, class LA, class LB>
+__device__ __forceinline__ void gemm_pipeline_sb(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[2][BN / 64]) {
+    // single LDS buffer: registers hold tile kt+1 while tile kt is consumed; two barriers per K-tile,
+    // half the LDS footprint -> one more workgroup per CU
+    constexpr int NB = BN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 3, kg = tid & 7;
+    float* As = lds;
+    float* Bs = lds + BM * LDT;
+    f32x4 ra[4], rb[NB];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ra[s] = la(s, 0);
+#pragma unroll
+    for (int s = 0; s < NB; ++s) rb[s] = lb(s, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(As + (lrow + 32 * s) * LDT + kg * 4) = ra[s];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * s) * LDT + kg * 4) = rb[s];
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ra[s] = la(s, kt + 1);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) rb[s] = lb(s, kt + 1);
+        }
+        mma_ktile<BN>(As, Bs, acc, wm, wn, lane);
+        __syncthreads();
+    }
+}
+
 template <int BN, class LA, class LB>
 __device__ __forceinline__ void gemm_pipeline(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[2][BN / 64]) {
     constexpr int NB = BN / 32;
@@ -123,12 +159,18 @@ __device__ __forceinline__ ConvRowInfo conv_row_info(int m, int npatch, int H, i
     return r;
 }
 
-template <int BN, bool SMALLC, bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3x3_relu_kernel(
+template <int BN, bool SMALLC, bool POOL, int VAR>
+__global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv3x3_relu_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
     constexpr int TN = BN / 64;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDT];
+    __shared__ __attribute__((aligned(16))) float lds[(VAR >= 2 ? 1 : 2) * (BM + BN) * LDT];
+    if constexpr (VAR == 1) {
+        // co-resident waves of one SIMD run the same program in lockstep and stall together at their
+        // barriers; give the wave in the even hardware slot static priority so the two desynchronise
+        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID[3:0] = wave slot
+        if ((hwid & 1u) == 0u) __builtin_amdgcn_s_setprio(1);
+    }
     __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
 
     const int tid = threadIdx.x;
@@ -191,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_relu_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    gemm_pipeline<BN>(la, lb, Kp / BK, lds, acc);
+    if constexpr (VAR >= 2) gemm_pipeline_sb<BN>(la, lb, Kp / BK, lds, acc);
+    else gemm_pipeline<BN>(la, lb, Kp / BK, lds, acc);
 
     // epilogue: bias + ReLU (+ 2x2 max over the 4 consecutive rows of a window)
     const int lane = tid & 63, wave = tid >> 6;
@@ -403,15 +446,34 @@ extern "C" int ntk_vgg_pack_weights(const float* w_hwio, float* w_packed, int ci
     return NTK_OK;
 }
 
-template <int BN, bool SMALLC>
-static void launch_conv(const float* in, const float* wp, const float* bias, float* out, int npatch,
-                        int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
+template <int BN, bool SMALLC, int VAR>
+static void launch_conv_v(const float* in, const float* wp, const float* bias, float* out, int npatch,
+                          int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
     const long rows = (long)npatch * 16;
     dim3 grid((unsigned)((rows + BM - 1) / BM), cout / BN);
     if (pool)
-        conv3x3_relu_kernel<BN, SMALLC, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        conv3x3_relu_kernel<BN, SMALLC, true, VAR><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
     else
-        conv3x3_relu_kernel<BN, SMALLC, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        conv3x3_relu_kernel<BN, SMALLC, false, VAR><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+}
+
+static int g_conv_variant = 2;   // tuning knob (ntk_vgg_set_conv_variant); every variant computes identical results
+
+template <int BN, bool SMALLC>
+static void launch_conv(const float* in, const float* wp, const float* bias, float* out, int npatch,
+                        int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
+    switch (g_conv_variant) {
+        case 1: launch_conv_v<BN, SMALLC, 1>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
+        case 2: launch_conv_v<BN, SMALLC, 2>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
+        case 3: launch_conv_v<BN, SMALLC, 3>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
+        default: launch_conv_v<BN, SMALLC, 0>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
+    }
+}
+
+extern "C" int ntk_vgg_set_conv_variant(int v) {
+    NTK_REQUIRE(v >= 0 && v <= 3, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d", v);
+    g_conv_variant = v;
+    return NTK_OK;
 }
 
 extern "C" int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, const float* bias,

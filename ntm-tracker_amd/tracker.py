@@ -73,7 +73,7 @@ class NTMOffsetTracker(object):
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  num_layers=1, read_head_size=4, write_head_size=1, write_first=False, init_scale=0.05,
                  learning_rate=1e-4, decay=0.95, momentum=0.9, max_gradient_norm=5.0, feature_channels=512,
-                 device="cuda", seed=42, vgg_chunk_frames=64):
+                 device="cuda", seed=42, vgg_chunk_frames=1024):
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)

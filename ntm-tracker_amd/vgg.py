@@ -63,7 +63,7 @@ class VGG16Conv43(object):
     weights: {layer_name: (w_hwio [3,3,Cin,Cout], b [Cout])} as numpy arrays or tensors.
     """
 
-    def __init__(self, weights, device="cuda", chunk_frames=64):
+    def __init__(self, weights, device="cuda", chunk_frames=1024):
         self.device = torch.device(device)
         self.chunk_frames = int(chunk_frames)
         self.packed = {}
