@@ -65,14 +65,24 @@ static void ntm_bwd_lds(const NtmDims& d, int T, int ldkT, int ldhT, NtmBwdLds& 
     L.total = o;
 }
 
-template <int MAXT>
+template <int MAXT, bool FIX>
 __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdLds L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const NtmDims& d = a.d;
-    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
-    const int N = d.N, Md = d.Md, MP = d.Md | 1, R = d.R, Wh = d.Wh, H = d.H, hid = d.hid;
-    const int S = d.S, K = d.K, PP = d.PP, RM = R * Md, SS = d.SS, NW = N >> 6, NMd = N * Md, HN = H * N;
-    const bool wf = d.write_first != 0;
+    const int b = blockIdx.x, tid0 = threadIdx.x, T = FIX ? 640 : blockDim.x;
+    const int N = FIX ? 128 : a.d.N, Md = FIX ? 20 : a.d.Md, MP = Md | 1, R = FIX ? 4 : a.d.R, Wh = FIX ? 1 : a.d.Wh;
+    const int H = R + Wh, hid = FIX ? 200 : a.d.hid, SS = FIX ? 3 : a.d.SS;
+    const int S = a.d.S, RM = R * Md, K = RM + hid, NW = N >> 6, NMd = N * Md, HN = H * N;
+    struct {
+        int O, oK, oB, oG, oS, oY, oE, oA, P, PP;
+    } d;
+    d.O = FIX ? 2 : a.d.O;
+    d.oK = 0; d.oB = H * Md; d.oG = d.oB + H; d.oS = d.oG + H; d.oY = d.oS + H * SS; d.oE = d.oY + H;
+    d.oA = d.oE + Wh * Md; d.P = d.oA + Wh * Md;
+    d.PP = (d.P + d.O + 3) & ~3;
+    const int PP = d.PP;
+    const bool wf = FIX ? false : (a.d.write_first != 0);
+    const int ldkT = FIX ? 280 : a.ldkT, ldhT = FIX ? 200 : a.ldhT;
+    int tid = tid0, lane = tid0 & 63;
 
     float* sPart = smem + L.part;
     float* sdM = smem + L.dM;  float* sG = smem + L.G;  float* sMp = smem + L.Mp;  float* sMt = smem + L.Mt;
@@ -86,13 +96,13 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
     f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
 
     // thread roles
-    const int hh = tid / N, nn = tid - hh * N;          // (head, slot) owner; active iff hh < H
-    const bool hn = hh < H;
-    const int wi = nn >> 6;
+    int hh = tid / N, nn = tid - hh * N;                // (head, slot) owner; active iff hh < H
+    bool hn = hh < H;
+    int wi = nn >> 6;
     const int nout = H * Md + Md + 2 * Wh * Md;
     const int nslP = min(max(1, T / nout), N);
     const int nperP = (N + nslP - 1) / nslP;
-    const int kg4 = a.ldkT >> 2, hg4 = a.ldhT >> 2;
+    const int kg4 = ldkT >> 2, hg4 = ldhT >> 2;
     const int nslZ = max(1, T / kg4), nperZ = (4 * hid + nslZ - 1) / nslZ;
     const int nslH = max(1, T / hg4), nperH = (PP + nslH - 1) / nslH;
     const int nslC = max(1, T / Md), nperC = (N + nslC - 1) / nslC;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
     for (int i = tid; i < NMd; i += T)
         sdM[(i / Md) * MP + (i % Md)] = a.dM_fin ? a.dM_fin[(size_t)b * NMd + i] : 0.f;
     for (int i = tid; i < HN; i += T) sdW[i] = a.dw_fin ? a.dw_fin[(size_t)b * HN + i] : 0.f;
-    for (int i = tid; i < a.ldkT; i += T) {
+    for (int i = tid; i < ldkT; i += T) {
         float v = 0.f;
         if (i < RM) v = a.dread_fin ? a.dread_fin[(size_t)b * RM + i] : 0.f;
         else if (i < K) v = a.dcs_fin ? a.dcs_fin[(size_t)b * 2 * hid + hid + (i - RM)] : 0.f;
@@ -172,6 +182,14 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
     };
 
     for (int t = S - 1; t >= 0; --t) {
+        // opaque thread id: keeps loop-invariant index/address expressions from being hoisted out of the
+        // t-loop (they would be spilled to scratch and reloaded every step)
+        {
+            int tid_op = tid0;
+            asm volatile("" : "+v"(tid_op));
+            tid = tid_op; lane = tid & 63;
+            hh = tid / N; nn = tid - hh * N; hn = hh < H; wi = nn >> 6;
+        }
         const size_t bt = (size_t)b * S + t;
         if (t > 0) prefetch(t - 1);
 
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         // ------------------------------------------------ B10: LSTM cell backward
         if (tid < hid) {
             float dh = sdZ[RM + tid];
-            for (int sl = 0; sl < nslH; ++sl) dh += sPart[sl * a.ldhT + tid];
+            for (int sl = 0; sl < nslH; ++sl) dh += sPart[sl * ldhT + tid];
             const f32x4 g = reinterpret_cast<const f32x4*>(sGt)[tid];
             const float gi = g[0], gj = g[1], gf = g[2], go = g[3];
             const float tc = tanhf(sCt[tid]);
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         __syncthreads();
         if (tid < K) {
             float s = 0.f;
-            for (int sl = 0; sl < nslZ; ++sl) s += sPart[sl * a.ldkT + tid];
+            for (int sl = 0; sl < nslZ; ++sl) s += sPart[sl * ldkT + tid];
             sdZ[tid] = s;
         }
         if (t > 0) commit();       // next (earlier) step's records: every reader of the old ones has passed a barrier
@@ -520,14 +538,19 @@ extern "C" int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int h
     NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_bwd: needs %zu B of LDS (> 160 KiB)", lds_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { ntk_set_error("ntk_ntm_seq_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
         attr_set = true;
     }
-    if (T <= 768) ntm_seq_bwd_kernel<768><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
-    else ntm_seq_bwd_kernel<1024><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    const bool fix = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2 &&
+                      T == 640 && !write_first && ldkT == 280 && ldhT == 200);
+    if (fix) ntm_seq_bwd_kernel<768, true><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else if (T <= 768) ntm_seq_bwd_kernel<768, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else ntm_seq_bwd_kernel<1024, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     NTK_CHECK_LAUNCH("ntk_ntm_seq_bwd");
     return NTK_OK;
 }

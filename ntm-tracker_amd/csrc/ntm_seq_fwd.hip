@@ -71,14 +71,25 @@ static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
     L.total = o;
 }
 
-template <int MAXT>
+// FIX = true specialises every dimension to the reference defaults the benchmark configs run
+// (direct_offset_output.py:21-27: mem 128x20, hidden 200, 4 read + 1 write heads, shift_range 1,
+// output_dim 2, 640 threads): index arithmetic constant-folds and the small loops unroll.
+template <int MAXT, bool FIX>
 __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const NtmDims& d = a.d;
-    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & 63;
-    const int N = d.N, Md = d.Md, MP = d.Md | 1, R = d.R, Wh = d.Wh, H = d.H, hid = d.hid;
-    const int S = d.S, K = d.K, PP = d.PP, RM = R * Md, SS = d.SS, NW = N >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, T = FIX ? 640 : blockDim.x;
+    const int N = FIX ? 128 : a.d.N, Md = FIX ? 20 : a.d.Md, MP = Md | 1, R = FIX ? 4 : a.d.R, Wh = FIX ? 1 : a.d.Wh;
+    const int H = R + Wh, hid = FIX ? 200 : a.d.hid, SS = FIX ? 3 : a.d.SS;
+    const int S = a.d.S, RM = R * Md, K = RM + hid, NW = N >> 6;
+    struct {
+        int O, oK, oB, oG, oS, oY, oE, oA, P, PP, ldz, ldh, write_first;
+    } d;
+    d.O = FIX ? 2 : a.d.O;
+    d.oK = 0; d.oB = H * Md; d.oG = d.oB + H; d.oS = d.oG + H; d.oY = d.oS + H * SS; d.oE = d.oY + H;
+    d.oA = d.oE + Wh * Md; d.P = d.oA + Wh * Md;
+    d.PP = (d.P + d.O + 3) & ~3; d.ldz = (K + 1 + 3) & ~3; d.ldh = (hid + 1 + 3) & ~3;
+    d.write_first = a.d.write_first;
+    const int PP = d.PP;
 
     float* sPart = smem + L.part;
     float* sM = smem + L.M;
@@ -119,7 +130,14 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
     const f32x4* Wa4 = reinterpret_cast<const f32x4*>(a.Wa);
     f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
 
+    const int tid0 = tid;
     for (int t = 0; t < S; ++t) {
+        // re-derive every thread-index expression inside the step: an opaque copy of the thread id keeps
+        // the compiler from hoisting dozens of loop-invariant addresses out of the t-loop and spilling them
+        int tid_op = tid0;
+        asm volatile("" : "+v"(tid_op));
+        const int tid = tid_op;
+        const int lane = tid & 63;
         const size_t bt = (size_t)b * S + t;
         // ------------------------------------------------------------ P1
         f32x4 xg = {0.f, 0.f, 0.f, 0.f};
@@ -136,12 +154,30 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             const int j = tid % hid, ks = tid / hid;
             const int k0 = ks * kper, k1 = min(K, k0 + kper);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* wp = Wr4 + (size_t)k0 * hid + j;
-#pragma unroll 8
-            for (int k = k0; k < k1; ++k, wp += hid) {
-                const float zk = sZ[k];
-                const f32x4 w = *wp;
-                acc += zk * w;
+            const f32x4* wp = Wr4 + j;
+            // rolling prefetch: two register batches of 8 rows keep >= 8 x 16 B per thread in flight from L2
+            constexpr int PF = 8;
+            f32x4 wa[PF], wb[PF];
+            const int klast = a.d.ldz - 1;          // last row of the Wr allocation (a zero pad row)
+#pragma unroll
+            for (int q = 0; q < PF; ++q) wa[q] = wp[(size_t)min(k0 + q, klast) * hid];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) wb[q] = wp[(size_t)min(k0 + PF + q, klast) * hid];
+            for (int k = k0; k < k1; k += 2 * PF) {
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const float zk = (k + q < k1) ? sZ[k + q] : 0.f;
+                    acc += zk * wa[q];
+                }
+#pragma unroll
+                for (int q = 0; q < PF; ++q) wa[q] = wp[(size_t)min(k + 2 * PF + q, klast) * hid];
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const float zk = (k + PF + q < k1) ? sZ[k + PF + q] : 0.f;
+                    acc += zk * wb[q];
+                }
+#pragma unroll
+                for (int q = 0; q < PF; ++q) wb[q] = wp[(size_t)min(k + 3 * PF + q, klast) * hid];
             }
             sPart4[ks * hid + j] = acc;
         }
@@ -411,14 +447,18 @@ extern "C" int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int h
                 "ntk_ntm_seq_fwd: state needs %zu B of LDS (> 160 KiB)", lds_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { ntk_set_error("ntk_ntm_seq_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
         attr_set = true;
     }
-    if (T <= 768) ntm_seq_fwd_kernel<768><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
-    else ntm_seq_fwd_kernel<1024><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    const bool fix = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2 && T == 640);
+    if (fix) ntm_seq_fwd_kernel<768, true><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else if (T <= 768) ntm_seq_fwd_kernel<768, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else ntm_seq_fwd_kernel<1024, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     NTK_CHECK_LAUNCH("ntk_ntm_seq_fwd");
     return NTK_OK;
 }

@@ -122,3 +122,25 @@ def test_unsupported_configs_fail_loudly(cuda):
     with pytest.raises(NtkError):                                   # mem_size must be a multiple of 64
         st = cell.zero_state(1)
         cell(torch.zeros((1, 8), device=cuda), st)
+
+
+def test_full_length_sequence_drift(cuda):
+    """BASELINE config-2 length (T=20 frames -> S=1300 strictly sequential steps): fp32 rounding must not
+    drift past the north_star tolerance (1e-4) against the float64 oracle on the quantity the tracker
+    consumes, tanh(logit), nor on the final memory."""
+    kw = CASES[0][1]
+    cfg, params, rng = _mk(kw, 514, 2, seed=123)
+    B, T = 2, 20
+    feats = np.maximum(rng.standard_normal((B, T, 64, 512)), 0).astype(np.float32)
+    x = O.serialize_inputs(feats, rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    _, logits, fin = O.loop_ntm_tracker(cfg, p64, x.astype(np.float64))
+    from ntmtrack.ntm import LoopNTMTracker
+    cell = _cell(cfg, params, cuda)
+    trk = LoopNTMTracker.__new__(LoopNTMTracker)
+    trk.cell, trk.initializer, trk.sequence_length = cell, None, T * 65
+    _o, l_gpu = trk(torch.from_numpy(x).to(cuda))
+    torch.cuda.synchronize()
+    err = np.max(np.abs(np.tanh(l_gpu.cpu().numpy()) - np.tanh(logits)))
+    assert err < 1e-4, err
+    assert np.max(np.abs(trk.last_state["M"].cpu().numpy() - fin["M"])) < 1e-4
