@@ -15,7 +15,7 @@
  *   - return value: NTK_OK (0) or a negative NTK_ERR_* code;
  *     ntk_last_error() returns a thread-local description of the last failure;
  *   - shapes are validated on the host before any launch: a bad shape is
- *     refused (NTK_ERR_BAD_SHAPE), never launched.
+ *     refused (NTK_ERR_BAD_SHAPE / NTK_ERR_UNSUPPORTED), never launched.
  */
 #ifndef NTMTRACK_H_
 #define NTMTRACK_H_
@@ -56,6 +56,11 @@ int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, const float
                              float* out, int frames, int H, int W, int cin, int cout,
                              int fuse_pool, void* stream);
 
+/* Tuning knob: 0 two LDS buffers / 2 workgroups per CU, 1 = 0 + static wave
+ * priority, 2 one LDS buffer / 3 workgroups per CU (default), 3 = 2 at 4
+ * workgroups per CU.  All variants compute bit-identical results. */
+int ntk_vgg_set_conv_variant(int variant);
+
 /* ------------------------------------------------------------------------
  * plain fp32 GEMMs used around the NTM recurrence (hoisted LSTM input
  * projection and the BPTT weight-gradient contractions)
@@ -75,6 +80,88 @@ size_t ntk_gemm_tn_workspace_bytes(int M, int N, int splits);
 int ntk_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     int M, int N, int K, int splits, int accumulate, float* workspace,
                     void* stream);
+
+/* out[cols][ldo] = in[rows][ldi]^T, zero padded to ldo (>= rows) */
+int ntk_transpose_pad(const float* in, int ldi, float* out, int ldo, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------
+ * NTM cell sequence kernels
+ * replaces: NTMCell.__call__ (ntm_cell.py:53-253) unrolled by LoopNTMTracker's
+ *           tf.while_loop (ntm_tracker_new.py:13-64), ops.py:135-158 (cosine
+ *           similarity, quirk Q1) and ops.py:180-242 (circular shift, quirk Q2)
+ *
+ * Packed parameter layouts (see ntm-tracker_amd/csrc/ntm_common.h):
+ *   WxT [4*hid][ldx]  Wr [ldz][4*hid] (row K = LSTM bias)  Wa [ldh][PP] (row hid = biases)
+ * with gate columns interleaved per unit (n' = unit*4 + gate, gate order i,j,f,o).
+ * --------------------------------------------------------------------- */
+
+/* control width P, padded widths and leading dimensions for a configuration */
+int ntk_ntm_padded_dims(int N, int Md, int R, int Wh, int hid, int shift_range, int O,
+                        int* P, int* PP, int* K, int* ldz, int* ldh);
+
+/* S steps of the cell for B sequences, one persistent workgroup per sequence.
+ * xproj [B,S,4*hid] = X * WxT^T (no bias).  State in: M0 [B,N,Md], w0 [B,H,N],
+ * read0 [B,R,Md], cs0 [B,2*hid] (c then h).  Out: logits [B,S,O], outputs
+ * (softmax, nullable), final state.  st_* (all nullable): per-step records
+ * = what LoopNTMTracker writes to its TensorArrays plus the BPTT stash. */
+int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int hid, int shift_range, int O,
+                    int write_first,
+                    const float* xproj, const float* Wr, const float* Wa,
+                    const float* M0, const float* w0, const float* read0, const float* cs0,
+                    float* logits, float* outputs,
+                    float* M_out, float* w_out, float* read_out, float* cs_out,
+                    float* st_z, float* st_gates, float* st_c, float* st_h, float* st_u,
+                    float* st_wc, float* st_wv, float* st_w, float* st_M, float* st_read,
+                    void* stream);
+
+/* Full BPTT through a recorded sequence (tf.gradients through the while_loop,
+ * direct_offset_output.py:611-621).  In: transposed weights WrT [4*hid][ldkT],
+ * WaT [PP][ldhT], the records, dlogits [B,S,O], optional gradient of the final
+ * state.  Out: raw gate gradients dgates [B,S,4*hid], raw control/logit
+ * gradients du [B,S,PP], gradient of the initial state. */
+int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int hid, int shift_range, int O,
+                    int write_first,
+                    const float* WrT, int ldkT, const float* WaT, int ldhT,
+                    const float* M0, const float* w0, const float* cs0,
+                    const float* st_gates, const float* st_c, const float* st_u,
+                    const float* st_wc, const float* st_wv, const float* st_w, const float* st_M,
+                    const float* dlogits,
+                    const float* dM_fin, const float* dw_fin, const float* dread_fin, const float* dcs_fin,
+                    float* dgates, float* du, float* dM0, float* dw0, float* dread0, float* dcs0,
+                    void* stream);
+
+/* trainable initial state (ntm_cell.py:284-315): out[b][i] = act(v[i]),
+ * act 0 = tanh, 1 = sigmoid; and its gradient summed over the batch */
+int ntk_ntm_init_state(const float* v, float* out, int n, int B, int act, void* stream);
+int ntk_ntm_init_state_bwd(const float* v, const float* dout, float* dv, int n, int B, int act,
+                           int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * tracking head (direct_offset_output.py)
+ * --------------------------------------------------------------------- */
+
+/* 64-point gather from conv4_3 (:392-399, receptive_field_sizes.py:135-143)
+ * + input serialiser (:439-500): fmap [B*T,Hf,Wf,C] -> X [B, T*(n*n+1), ldx]
+ * rows [feat(C), delimiter, target, 0 pad]; gts0 [B, n*n] = frame-0 heat-map
+ * (nullable -> zeros). */
+int ntk_gather_serialize(const float* fmap, const float* gts0, float* X, int B, int T,
+                         int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
+                         int grid_n, void* stream);
+
+/* output gather + tanh + l2 loss (:581-606) and its gradient:
+ * pred [B,T-1,O] (nullable), loss [1], dlogits [B,S,O] (nullable). */
+int ntk_offset_loss(const float* logits, const float* offsets, float* pred, float* loss,
+                    float* dlogits, int B, int T, int NF, int O, void* stream);
+
+/* ------------------------------------------------------------------------
+ * optimiser (direct_offset_output.py:620-626): tf.clip_by_global_norm +
+ * tf.train.RMSPropOptimizer on one flat buffer
+ * --------------------------------------------------------------------- */
+size_t ntk_global_norm_workspace_bytes(size_t n);
+int ntk_global_norm(const float* grads, size_t n, float* workspace, float* gnorm, void* stream);
+int ntk_rmsprop_clip_step(float* params, const float* grads, float* ms, float* mom, size_t n,
+                          float lr, float decay, float momentum, float eps, float clip_norm,
+                          const float* gnorm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@ sum (direct_offset_output.py:606).
 import torch
 
 from . import _lib
+from . import parallel
 from .ntm import NTMCell, _P, _np
 from .vgg import VGG16Conv43
 
@@ -156,9 +157,7 @@ class NTMOffsetTracker(object):
         s_ntm.wait_event(done)
         with torch.cuda.stream(s_ntm):
             loss, _pred = self.loss_and_grads(slot["buf"], gts0, offsets)
-            if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                    torch.distributed.get_world_size() > 1:
-                torch.distributed.all_reduce(self.cell.params.grad, op=torch.distributed.ReduceOp.SUM)
+            parallel.allreduce_gradients(self.cell.params.grad)
             self.opt.step()
             slot["free"] = torch.cuda.Event()
             slot["free"].record(s_ntm)
@@ -176,8 +175,6 @@ class NTMOffsetTracker(object):
         Returns the (local) loss as a 1-element device tensor."""
         fmap = self.features(frames)
         loss, _pred = self.loss_and_grads(fmap, gts0, offsets)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1:
-            torch.distributed.all_reduce(self.cell.params.grad, op=torch.distributed.ReduceOp.SUM)
+        parallel.allreduce_gradients(self.cell.params.grad)
         self.opt.step()
         return loss

@@ -1,0 +1,60 @@
+"""CPU: host-side logic of the product package that needs no GPU -- packed parameter layout,
+dimension bookkeeping, flop accounting, data contract helpers."""
+import numpy as np
+import torch
+
+from oracle import ntm_oracle as O
+
+
+def test_packed_params_roundtrip_and_layout():
+    from ntmtrack.ntm import NTMDims, PackedParams
+    d = NTMDims(514, 2, 128, 20, 1, 200, 4, 1)
+    assert (d.P, d.PP, d.K, d.ldx, d.ldz, d.ldh) == (170, 172, 280, 516, 284, 204)
+    cfg = O.NTMConfig(514, 2, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=200,
+                      controller_num_layers=1, write_head_size=1, read_head_size=4)
+    assert cfg.control_dim == d.P
+    rng = np.random.default_rng(0)
+    p = O.init_params(cfg, rng)
+    p["lstm/cell_0/biases"] = rng.standard_normal(800).astype(np.float32)
+    p["addressing/biases"] = rng.standard_normal(170).astype(np.float32)
+    p["output/biases"] = rng.standard_normal(2).astype(np.float32)
+    pk = PackedParams(d, "cpu")
+    pk.load_tf({k: torch.from_numpy(v) for k, v in p.items()})
+    back = pk.to_tf()
+    for k in p:
+        assert np.array_equal(back[k].numpy(), p[k]), k
+    # trainable element count and the structural zero padding
+    assert sum(v.size for v in p.values()) == 673852
+    assert int((pk.flat != 0).sum()) <= 673852
+    # the packed gate product equals the TF-layout one: [x;read;h] @ W + b with columns regrouped per unit
+    x = rng.standard_normal(514).astype(np.float32)
+    z = rng.standard_normal(280).astype(np.float32)
+    g_tf = np.concatenate([x, z]) @ p["lstm/cell_0/weights"] + p["lstm/cell_0/biases"]
+    WxT, Wr = pk.view("WxT").numpy(), pk.view("Wr").numpy()
+    g_pk = WxT[:, :514] @ x + z @ Wr[:280] + Wr[280]
+    np.testing.assert_allclose(g_pk.reshape(200, 4).T.reshape(-1), g_tf, rtol=1e-5, atol=1e-5)
+    # unpack/output linear
+    h = rng.standard_normal(200).astype(np.float32)
+    Wa = pk.view("Wa").numpy()
+    u = h @ Wa[:200] + Wa[200]
+    np.testing.assert_allclose(u[:170], h @ p["addressing/weights"] + p["addressing/biases"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(u[170:172], h @ p["output/weights"] + p["output/biases"], rtol=1e-5, atol=1e-5)
+
+
+def test_conv_flop_accounting_matches_survey():
+    from ntmtrack.vgg import conv_flops_per_frame, VGG_LAYERS
+    assert conv_flops_per_frame() == 2 * 13959364608            # 13.959 GMAC / frame
+    assert [l[0] for l in VGG_LAYERS] == [l[0] for l in O.VGG_LAYERS]
+
+
+def test_shard_range_partitions_sequences():
+    from ntmtrack import parallel
+    assert parallel.shard_range(64, 0, 1) == (0, 64)
+    spans = [parallel.shard_range(512, r, 8) for r in range(8)]
+    assert spans[0] == (0, 64) and spans[7] == (448, 512)
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
+    try:
+        parallel.shard_range(10, 0, 4)
+        assert False
+    except ValueError:
+        pass
