@@ -137,6 +137,25 @@ int ntk_ntm_init_state_bwd(const float* v, const float* dout, float* dv, int n, 
                            int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------
+ * DNC core sequence kernel (forward)
+ * replaces: dnc.DNC._build (dnc/dnc.py:84-127) unrolled by tf.nn.dynamic_rnn
+ *           (direct_offset_output_with_dnc.py:66-88): snt.LSTM controller,
+ *           MemoryAccess (dnc/access.py:113-303), CosineWeights / TemporalLinkage /
+ *           Freeness (dnc/addressing.py), output linear, clip_value.
+ * Packed parameters: Wr [ldz][4*hid] (rows [reads ; h], row K = b_gates, columns
+ * unit*4+gate), Wi [ldh][IP] = the ten interface linears side by side in the order
+ * write_vectors, erase_vectors, free_gate, allocation_gate, write_gate, read_mode,
+ * write_keys, write_strengths, read_keys, read_strengths (row hid = biases),
+ * Wy [ldy][OP] (rows [h ; reads], row Ky = bias).  State tensors are updated IN PLACE.
+ * --------------------------------------------------------------------- */
+int ntk_dnc_padded_dims(int N, int W, int R, int Wn, int hid, int O,
+                        int* I, int* IP, int* K, int* ldz, int* ldh, int* Ky, int* ldy, int* OP);
+int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value,
+                    const float* xproj, const float* Wr, const float* Wi, const float* Wy,
+                    float* mem, float* link, float* usage, float* rw, float* ww, float* prec,
+                    float* reads, float* hc, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * tracking head (direct_offset_output.py)
  * --------------------------------------------------------------------- */
 

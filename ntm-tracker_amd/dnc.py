@@ -1,0 +1,166 @@
+"""DNC core on the HIP sequence kernel.
+
+Mirrors the reference operator interface (dnc/dnc.py:36-142, vendored DeepMind DNC):
+  ``DNC(access_config={'memory_size','word_size','num_reads','num_writes'},
+        controller_config={'hidden_size'}, output_size, clip_value=None)``,
+  ``core(inputs, prev_state) -> (output, DNCState)``, ``initial_state(batch_size)``,
+  ``state_size`` / ``output_size``; and ``run_model(input_sequence[S,B,D], output_size)``
+  of direct_offset_output_with_dnc.py:66-88 (time-major dynamic_rnn).
+State tuples are the reference's namedtuples holding device tensors.
+"""
+import collections
+import ctypes
+
+import torch
+
+from . import _lib
+from .ntm import gemm_nt
+
+_P = _lib.ptr
+
+DNCState = collections.namedtuple("DNCState", ("access_output", "access_state", "controller_state"))
+AccessState = collections.namedtuple("AccessState", ("memory", "read_weights", "write_weights", "linkage", "usage"))
+TemporalLinkageState = collections.namedtuple("TemporalLinkageState", ("link", "precedence_weights"))
+LSTMState = collections.namedtuple("LSTMState", ("hidden", "cell"))
+
+# order of the ten interface linears inside the packed Wi matrix (csrc/dnc_seq_fwd.hip: DncDims)
+INTERFACE = ("write_vectors", "erase_vectors", "free_gate", "allocation_gate", "write_gate", "read_mode",
+             "write_keys", "write_strengths", "read_keys", "read_strengths")
+
+
+class DNC(object):
+    def __init__(self, access_config, controller_config, output_size, clip_value=None, input_dim=None,
+                 device="cuda", seed=0):
+        self.N = int(access_config.get("memory_size", 128))
+        self.W = int(access_config.get("word_size", 20))
+        self.R = int(access_config.get("num_reads", 1))
+        self.Wn = int(access_config.get("num_writes", 1))
+        self.hid = int(controller_config["hidden_size"])
+        self.O = int(output_size)
+        self.clip_value = float(clip_value or 0)
+        self.device = torch.device(device)
+        self.seed = seed
+        vals = [ctypes.c_int() for _ in range(8)]
+        _lib.check(_lib.lib().ntk_dnc_padded_dims(self.N, self.W, self.R, self.Wn, self.hid, self.O,
+                                                  *[ctypes.byref(v) for v in vals]), "ntk_dnc_padded_dims")
+        self.I, self.IP, self.K, self.ldz, self.ldh, self.Ky, self.ldy, self.OP = [v.value for v in vals]
+        self.D = None
+        if input_dim is not None:
+            self._build(int(input_dim))
+
+    # ---- parameters (Sonnet v1 names)
+    def interface_widths(self):
+        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        return dict(write_vectors=Wn * W, erase_vectors=Wn * W, free_gate=R, allocation_gate=Wn, write_gate=Wn,
+                    read_mode=R * (1 + 2 * Wn), write_keys=Wn * W, write_strengths=Wn, read_keys=R * W, read_strengths=R)
+
+    def _build(self, input_dim, sd=None):
+        self.D = input_dim
+        self.ldx = (input_dim + 3) // 4 * 4
+        if sd is None:
+            g = torch.Generator().manual_seed(int(self.seed))
+            tn = lambda fan_in, *shape: torch.clamp(torch.randn(shape, generator=g), -2, 2) / fan_in ** 0.5
+            in_dim = input_dim + self.R * self.W + self.hid
+            sd = {"lstm/w_gates": tn(in_dim, in_dim, 4 * self.hid), "lstm/b_gates": torch.zeros(4 * self.hid)}
+            for name, width in self.interface_widths().items():
+                sd["memory_access/%s/w" % name] = tn(self.hid, self.hid, width)
+                sd["memory_access/%s/b" % name] = torch.zeros(width)
+            sd["output_linear/w"] = tn(self.Ky, self.Ky, self.O)
+            sd["output_linear/b"] = torch.zeros(self.O)
+        self.load_state_dict(sd, input_dim)
+
+    def load_state_dict(self, sd, input_dim=None):
+        t = lambda v: torch.as_tensor(v, dtype=torch.float32)
+        W = t(sd["lstm/w_gates"])
+        if input_dim is None:
+            input_dim = W.shape[0] - self.R * self.W - self.hid
+        self.D, self.ldx = int(input_dim), (int(input_dim) + 3) // 4 * 4
+        hid, dev = self.hid, self.device
+        assert tuple(W.shape) == (self.D + self.K, 4 * hid), W.shape
+        perm = torch.arange(4 * hid).view(4, hid).t().reshape(-1)          # gate-major -> unit-major columns
+        Wp, bp = W[:, perm], t(sd["lstm/b_gates"])[perm]
+        WxT = torch.zeros((4 * hid, self.ldx))
+        WxT[:, :self.D] = Wp[:self.D].t()
+        Wr = torch.zeros((self.ldz, 4 * hid))
+        Wr[:self.K] = Wp[self.D:]
+        Wr[self.K] = bp
+        Wi = torch.zeros((self.ldh, self.IP))
+        o = 0
+        for name in INTERFACE:
+            w, b_ = t(sd["memory_access/%s/w" % name]), t(sd["memory_access/%s/b" % name])
+            Wi[:hid, o:o + w.shape[1]] = w
+            Wi[hid, o:o + w.shape[1]] = b_
+            o += w.shape[1]
+        assert o == self.I
+        Wy = torch.zeros((self.ldy, self.OP))
+        Wy[:self.Ky, :self.O] = t(sd["output_linear/w"])
+        Wy[self.Ky, :self.O] = t(sd["output_linear/b"])
+        self.WxT, self.Wr, self.Wi, self.Wy = WxT.to(dev), Wr.to(dev), Wi.to(dev), Wy.to(dev)
+        self._sd = {k: t(v).clone() for k, v in sd.items()}
+
+    def state_dict(self):
+        return {k: v.clone() for k, v in self._sd.items()}
+
+    # ---- state
+    def initial_state(self, batch_size, dtype=torch.float32):
+        """dnc.py:129-134: all zeros (not trainable)."""
+        z = lambda *s: torch.zeros(s, device=self.device, dtype=torch.float32)
+        B, N, W, R, Wn = batch_size, self.N, self.W, self.R, self.Wn
+        return DNCState(
+            access_output=z(B, R, W),
+            access_state=AccessState(z(B, N, W), z(B, R, N), z(B, Wn, N), TemporalLinkageState(z(B, Wn, N, N), z(B, Wn, N)), z(B, N)),
+            controller_state=LSTMState(z(B, self.hid), z(B, self.hid)))
+
+    @property
+    def state_size(self):
+        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        return DNCState(R * W, AccessState((N, W), (R, N), (Wn, N), TemporalLinkageState((Wn, N, N), (Wn, N)), (N,)),
+                        LSTMState((self.hid,), (self.hid,)))
+
+    @property
+    def output_size(self):
+        return (self.O,)
+
+    # ---- sequence kernel: inputs time-major [S,B,D] like dynamic_rnn(time_major=True)
+    def run_sequence(self, inputs_tm, prev_state=None):
+        S, B, D = inputs_tm.shape
+        if self.D is None:
+            self._build(D)
+        if D != self.D:
+            raise _lib.NtkError("inputs have %d features, the core was built for %d" % (D, self.D))
+        dev = self.device
+        X = torch.zeros((B, S, self.ldx), device=dev)
+        X[:, :, :D] = inputs_tm.transpose(0, 1)
+        xproj = gemm_nt(X.view(B * S, self.ldx), self.WxT)
+        st = prev_state or self.initial_state(B)
+        acc = st.access_state
+        # the kernel updates the state in place: work on private copies
+        mem, link = acc.memory.clone().contiguous(), acc.linkage.link.clone().contiguous()
+        usage, rw, ww = acc.usage.clone().contiguous(), acc.read_weights.clone().contiguous(), acc.write_weights.clone().contiguous()
+        prec, reads = acc.linkage.precedence_weights.clone().contiguous(), st.access_output.clone().contiguous()
+        hc = torch.cat([st.controller_state.hidden, st.controller_state.cell], dim=1).contiguous()
+        out = torch.empty((B, S, self.O), device=dev)
+        _lib.check(_lib.lib().ntk_dnc_seq_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value,
+                                              _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
+                                              _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), _lib.stream()),
+                   "ntk_dnc_seq_fwd")
+        new = DNCState(reads, AccessState(mem, rw, ww, TemporalLinkageState(link, prec), usage),
+                       LSTMState(hc[:, :self.hid].contiguous(), hc[:, self.hid:].contiguous()))
+        return out.transpose(0, 1), new          # time-major [S,B,O]
+
+    def __call__(self, inputs, prev_state):
+        """One step of the core: (output [B,O], DNCState), dnc.py:84-127."""
+        y, new = self.run_sequence(inputs.unsqueeze(0), prev_state)
+        return y[0], new
+
+
+def run_model(input_sequence, output_size, core=None, **flags):
+    """direct_offset_output_with_dnc.py:66-88 with FLAGS passed as keyword arguments:
+    mem_size, mem_dim, read_head_size, write_head_size, hidden_size, clip_value."""
+    if core is None:
+        core = DNC({"memory_size": flags.get("mem_size", 128), "word_size": flags.get("mem_dim", 20),
+                    "num_reads": flags.get("read_head_size", 4), "num_writes": flags.get("write_head_size", 1)},
+                   {"hidden_size": flags.get("hidden_size", 200)}, output_size, flags.get("clip_value", 20),
+                   device=input_sequence.device)
+    out, _ = core.run_sequence(input_sequence, core.initial_state(input_sequence.shape[1]))
+    return out

@@ -1,0 +1,115 @@
+"""GPU parity: DNC core sequence kernel vs the numpy oracle (oracle/dnc_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dnc_oracle as D
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, D, O, N, W, R, Wn, hid, clip, S, B, start from the all-zero initial_state?
+    ("small_multiwrite", 10, 3, 16, 8, 2, 3, 16, 20.0, 6, 2, False),
+    ("c3_shape", 514, 2, 256, 64, 4, 1, 200, 20.0, 8, 2, True),
+    ("no_clip_odd", 12, 2, 40, 12, 3, 2, 24, 0.0, 5, 1, False),
+    ("c5_shape_short", 514, 2, 512, 128, 4, 1, 200, 20.0, 3, 1, True),
+    ("c3_shape_random_state", 514, 2, 256, 64, 4, 1, 200, 20.0, 4, 2, False),
+]
+
+
+def _random_state(cfg, B, rng):
+    """A valid, NON-DEGENERATE access state: distinct usages (no near-ties for the allocation sort: with
+    several write heads and exactly tied usages the winner of the sort hinges on the last fp32 bit in any
+    implementation -- the reference's own tests plant distinct usages for the same reason,
+    addressing_test.py:328-333), sub-stochastic weights and link."""
+    a = cfg.access
+    N, W, R, Wn = a.N, a.W, a.R, a.Wn
+    f = lambda *s: rng.random(s).astype(np.float32)
+    usage = np.stack([rng.permutation(N) for _ in range(B)]).astype(np.float32) / N * 0.8 + 0.1
+    rw = f(B, R, N); rw /= rw.sum(2, keepdims=True) + 1
+    ww = f(B, Wn, N); ww /= ww.sum(2, keepdims=True) + 1
+    prec = f(B, Wn, N); prec /= prec.sum(2, keepdims=True) + 1
+    link = f(B, Wn, N, N)
+    link /= np.maximum(link.sum(2, keepdims=True), 1)
+    link /= np.maximum(link.sum(3, keepdims=True), 1)
+    link[:, :, np.arange(N), np.arange(N)] = 0
+    mem = (f(B, N, W) - 0.5).astype(np.float32)
+    acc = D.AccessState(mem, rw, ww, D.TemporalLinkageState(link.astype(np.float32), prec), usage)
+    reads = (rw @ mem).astype(np.float32)
+    h, c = (f(B, cfg.hid) - 0.5), (f(B, cfg.hid) - 0.5)
+    return D.DNCState(reads, acc, D.LSTMState(h, c))
+
+
+@pytest.mark.parametrize("name,Din,O,N,W,R,Wn,hid,clip,S,B,zero", CASES, ids=[c[0] for c in CASES])
+def test_dnc_sequence_matches_oracle(cuda, name, Din, O, N, W, R, Wn, hid, clip, S, B, zero):
+    from ntmtrack.dnc import DNC
+    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=Wn, hidden_size=hid, clip_value=clip)
+    rng = np.random.default_rng(5)
+    p = D.init_params(cfg, rng)
+    for k in p:                                      # non-zero biases; stronger interface so gates/keys are not all ~0.5
+        if k.endswith("/b") or k.endswith("b_gates"):
+            p[k] = rng.uniform(-0.3, 0.3, size=p[k].shape).astype(np.float32)
+        if k.startswith("memory_access/") and k.endswith("/w"):
+            p[k] = (p[k] * 6).astype(np.float32)
+    x = rng.standard_normal((S, B, Din)).astype(np.float32)
+    # The oracle runs in float32 here on purpose: the allocation weighting sorts usage, and slots that were
+    # never specifically written carry mathematically tied usages (they differ at 1e-12 relative in float64 and
+    # are exact ties in float32, broken by index as tf.nn.top_k does).  A float64 oracle would order those
+    # near-ties differently from ANY float32 implementation, the reference's TF graph included.
+    st0 = None if zero else _random_state(cfg, B, rng)
+    ys, fin = D.run_model(cfg, p, x, state=st0)
+
+    from ntmtrack import dnc as G
+    core = DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": Wn}, {"hidden_size": hid}, O, clip, device=cuda)
+    core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    gst = None
+    if st0 is not None:
+        t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(cuda)
+        a0 = st0.access_state
+        gst = G.DNCState(t(st0.access_output), G.AccessState(t(a0.memory), t(a0.read_weights), t(a0.write_weights),
+                         G.TemporalLinkageState(t(a0.linkage.link), t(a0.linkage.precedence_weights)), t(a0.usage)),
+                         G.LSTMState(t(st0.controller_state.hidden), t(st0.controller_state.cell)))
+    out, st = core.run_sequence(torch.from_numpy(x).to(cuda), gst)
+    torch.cuda.synchronize()
+    tol = dict(atol=5e-5, rtol=0)
+    np.testing.assert_allclose(out.cpu().numpy(), ys, **tol)
+    acc = st.access_state
+    np.testing.assert_allclose(acc.memory.cpu().numpy(), fin.access_state.memory, err_msg="memory", **tol)
+    np.testing.assert_allclose(acc.usage.cpu().numpy(), fin.access_state.usage, err_msg="usage", **tol)
+    np.testing.assert_allclose(acc.write_weights.cpu().numpy(), fin.access_state.write_weights, err_msg="ww", **tol)
+    np.testing.assert_allclose(acc.read_weights.cpu().numpy(), fin.access_state.read_weights, err_msg="rw", **tol)
+    np.testing.assert_allclose(acc.linkage.link.cpu().numpy(), fin.access_state.linkage.link, err_msg="link", **tol)
+    np.testing.assert_allclose(acc.linkage.precedence_weights.cpu().numpy(), fin.access_state.linkage.precedence_weights, err_msg="prec", **tol)
+    np.testing.assert_allclose(st.access_output.cpu().numpy(), fin.access_output, err_msg="reads", **tol)
+    np.testing.assert_allclose(st.controller_state.hidden.cpu().numpy(), fin.controller_state.hidden, err_msg="h", **tol)
+    np.testing.assert_allclose(st.controller_state.cell.cpu().numpy(), fin.controller_state.cell, err_msg="c", **tol)
+    # structural properties the reference tests assert (addressing_test.py:208-216)
+    link = acc.linkage.link.cpu().numpy()
+    assert link.min() >= -1e-6 and link.max() <= 1 + 1e-6
+    assert np.abs(link[:, :, range(N), range(N)]).max() == 0
+
+
+def test_dnc_step_api_and_state_chaining(cuda):
+    """core(inputs, prev_state) one step at a time == one launch over the sequence; initial_state is all zeros."""
+    from ntmtrack.dnc import DNC, DNCState
+    core = DNC({"memory_size": 32, "word_size": 8, "num_reads": 2, "num_writes": 1}, {"hidden_size": 32}, 2, 20, input_dim=10,
+               device=cuda, seed=3)
+    st = core.initial_state(2)
+    assert isinstance(st, DNCState) and not st.access_state.memory.any() and not st.access_state.linkage.link.any()
+    x = torch.randn((4, 2, 10), generator=torch.Generator().manual_seed(0)).to(cuda)
+    full, fin = core.run_sequence(x)
+    outs = []
+    for t in range(4):
+        y, st = core(x[t], st)
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert torch.allclose(torch.stack(outs, 0), full, atol=1e-6)
+    assert torch.allclose(st.access_state.memory, fin.access_state.memory, atol=1e-6)
+
+
+def test_dnc_unsupported_shapes_fail_loudly(cuda):
+    from ntmtrack.dnc import DNC
+    from ntmtrack._lib import NtkError
+    core = DNC({"memory_size": 20, "word_size": 6, "num_reads": 2, "num_writes": 3}, {"hidden_size": 16}, 2, 20, input_dim=10, device=cuda)
+    with pytest.raises(NtkError):                    # word_size 6 is not a multiple of 4 (reference test shape)
+        core.run_sequence(torch.zeros((2, 1, 10), device=cuda))
