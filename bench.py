@@ -102,8 +102,8 @@ def cpu_baseline(ws, n_vgg_frames=4, T=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--seq-len", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -132,6 +132,11 @@ class DNC(object):
         X = torch.zeros((B, S, self.ldx), device=dev)
         X[:, :, :D] = inputs_tm.transpose(0, 1)
         xproj = gemm_nt(X.view(B * S, self.ldx), self.WxT)
+        return self.run_projected(xproj, B, S, prev_state)
+
+    def run_projected(self, xproj, B, S, prev_state=None):
+        """Sequence kernel on an already projected input (xproj [B*S, 4*hid] = X WxT^T)."""
+        dev = self.device
         st = prev_state or self.initial_state(B)
         acc = st.access_state
         # the kernel updates the state in place: work on private copies

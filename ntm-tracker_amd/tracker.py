@@ -178,3 +178,36 @@ class NTMOffsetTracker(object):
         parallel.allreduce_gradients(self.cell.params.grad)
         self.opt.step()
         return loss
+
+
+class DNCOffsetTracker(object):
+    """VGG-16 conv4_3 + DNC core offsets tracker (direct_offset_output_with_dnc.py:408-648), forward path:
+    frames -> VGG -> 64-point gather + serialise -> time-major dynamic_rnn over dnc.DNC (clip_value 20)
+    -> output gather at the delimiter steps -> tanh.  Defaults from :22-43 (mem 128x20, R4/W1, hidden 200)."""
+
+    def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
+                 read_head_size=4, write_head_size=1, clip_value=20, feature_channels=512, device="cuda", seed=42,
+                 vgg_chunk_frames=1024):
+        from .dnc import DNC
+        self.B, self.T = int(batch_size), int(sequence_length)
+        self.S = self.T * (NUM_FEATURES + 1)
+        self.device = torch.device(device)
+        self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames) if vgg_weights else None
+        self.core = DNC({"memory_size": mem_size, "word_size": mem_dim, "num_reads": read_head_size,
+                         "num_writes": write_head_size}, {"hidden_size": hidden_size}, 2, clip_value,
+                        input_dim=feature_channels + 2, device=self.device, seed=seed)
+
+    def forward_features(self, fmap, gts0):
+        """-> logits [B,S,2] (batch-major view of the time-major core output, _with_dnc.py:534-541)."""
+        X = gather_serialize(fmap, gts0, self.B, self.T, self.core.ldx)
+        xproj = __import__("ntmtrack.ntm", fromlist=["gemm_nt"]).gemm_nt(X.view(self.B * self.S, self.core.ldx), self.core.WxT)
+        out_tm, state = self.core.run_projected(xproj, self.B, self.S)
+        return out_tm.transpose(0, 1).contiguous(), state
+
+    def infer(self, frames, gts0):
+        if self.vgg is None:
+            raise _lib.NtkError("tracker was built without VGG weights")
+        logits, _ = self.forward_features(self.vgg(frames), gts0)
+        offs = torch.zeros((self.B, self.T, 2), device=self.device)
+        _loss, pred, _ = offset_loss(logits, offs, self.T, want_grad=False)
+        return pred

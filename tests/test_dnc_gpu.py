@@ -113,3 +113,28 @@ def test_dnc_unsupported_shapes_fail_loudly(cuda):
     core = DNC({"memory_size": 20, "word_size": 6, "num_reads": 2, "num_writes": 3}, {"hidden_size": 16}, 2, 20, input_dim=10, device=cuda)
     with pytest.raises(NtkError):                    # word_size 6 is not a multiple of 4 (reference test shape)
         core.run_sequence(torch.zeros((2, 1, 10), device=cuda))
+
+
+def test_dnc_offset_tracker_pipeline(cuda):
+    """direct_offset_output_with_dnc forward: conv4_3 map -> gather/serialise -> DNC(clip 20) -> tanh at the
+    delimiter steps, vs the oracle chain (serialize_inputs -> run_model time-major -> offset gather)."""
+    from oracle import ntm_oracle as O
+    from ntmtrack import tracker
+    B, T = 2, 2
+    rng = np.random.default_rng(4)
+    trk = tracker.DNCOffsetTracker(B, T, vgg_weights=None, mem_size=64, mem_dim=16, hidden_size=32, read_head_size=2,
+                                   write_head_size=1, clip_value=20, device=cuda, seed=9)
+    sd = {k: v.numpy() for k, v in trk.core.state_dict().items()}
+    cfg = D.DNCConfig(514, 2, memory_size=64, word_size=16, num_reads=2, num_writes=1, hidden_size=32, clip_value=20)
+    fmap = np.maximum(rng.standard_normal((B * T, 28, 28, 512)), 0).astype(np.float32)
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    x = O.serialize_inputs(O.extract_features(fmap).reshape(B, T, 64, 512), gts)          # [B,S,514]
+    ys, _ = D.run_model(cfg, sd, np.ascontiguousarray(np.transpose(x, (1, 0, 2))))       # time-major
+    logits_ref = np.transpose(ys, (1, 0, 2))
+    _, pred_ref = O.offset_loss(logits_ref, np.zeros((B, T, 2), np.float32))
+    logits, _ = trk.forward_features(torch.from_numpy(fmap).to(cuda), torch.from_numpy(gts[:, 0].copy()).to(cuda))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logits.cpu().numpy(), logits_ref, atol=5e-5)
+    offs = torch.zeros((B, T, 2), device=cuda)
+    _l, pred, _ = tracker.offset_loss(logits, offs, T, want_grad=False)
+    np.testing.assert_allclose(pred.cpu().numpy(), pred_ref, atol=5e-5)
