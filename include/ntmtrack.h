@@ -44,7 +44,9 @@ const char* ntk_last_error(void);
  * --------------------------------------------------------------------- */
 
 /* Repack TF HWIO weights [3,3,Cin,Cout] into the kernel's [Cout][Kp] layout,
- * k = (ky*3+kx)*Cin + c, Kp = ntk_vgg_packed_k(Cin) (zero padded). */
+ * Kp = ntk_vgg_packed_k(Cin) (zero padded); for Cin % 32 == 0 the K order is
+ * 32-channel chunk outer / tap inner: k = (c/32)*288 + (ky*3+kx)*32 + c%32;
+ * for Cin = 3: k = (ky*3+kx)*Cin + c. */
 int ntk_vgg_packed_k(int cin);
 int ntk_vgg_pack_weights(const float* w_hwio, float* w_packed, int cin, int cout, void* stream);
 

@@ -174,8 +174,15 @@ __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv
     __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
 
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order (1-D grid): workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch, speed
+    // only).  Inside an XCD consecutive workgroups take the column tiles of ONE row tile, so the A rows that
+    // every column tile re-reads are served by that XCD's L2 instead of being fetched once per column tile.
+    const int ctiles = Cout / BN;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int rt = (li / ctiles) * 8 + xcd;
+    const int m0 = rt * BM;
+    const int n0 = (li % ctiles) * BN;
+    if (m0 >= npatch * 16) return;
     if (tid < BM) {
         ConvRowInfo ri = conv_row_info(m0 + tid, npatch, H, W);
         s_pix[tid] = ri.pix; s_yx[tid] = ri.yx; s_ppix[tid] = ri.ppix;
@@ -194,9 +201,10 @@ __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv
     auto la = [&](int s, int kt) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if constexpr (!SMALLC) {
-            const int kk0 = kt * BK;
-            const int tap = kk0 / Cin;            // Cin % 32 == 0: a K-tile never straddles taps
-            const int c0 = kk0 - tap * Cin;
+            // K order: 32-channel chunk outer, the 9 taps inner -- the nine shifted reads of one channel chunk are
+            // consecutive K-tiles, so their overlapping 128-B lines are re-read while still L2 (mostly L1) resident
+            const int chunk = kt / 9, tap = kt - chunk * 9;
+            const int c0 = chunk * BK;
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
             const int yy = ry[s] + dy, xx = rx[s] + dx;
             if (rpix[s] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
@@ -268,13 +276,19 @@ __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv
     }
 }
 
-// HWIO [3,3,Cin,Cout] -> [Cout][Kp], k = tap*Cin + c
+// HWIO [3,3,Cin,Cout] -> [Cout][Kp].  Cin % 32 == 0: k = (c/32)*288 + tap*32 + c%32 (chunk outer, tap inner);
+// tiny Cin (conv1_1): k = tap*Cin + c, zero padded to Kp.
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int Kp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Cout * Kp) return;
     const int n = idx / Kp, k = idx - n * Kp;
     float v = 0.f;
-    if (k < 9 * Cin) v = w[(size_t)k * Cout + n];   // HWIO flat index = (tap*Cin + c)*Cout + n
+    if (k < 9 * Cin) {
+        int tap, c;
+        if ((Cin % BK) == 0) { const int chunk = k / (9 * BK), r = k - chunk * 9 * BK; tap = r / BK; c = chunk * BK + (r - tap * BK); }
+        else { tap = k / Cin; c = k - tap * Cin; }
+        v = w[(size_t)(tap * Cin + c) * Cout + n];   // HWIO flat index = (tap*Cin + c)*Cout + n
+    }
     wp[idx] = v;
 }
 
@@ -450,7 +464,8 @@ template <int BN, bool SMALLC, int VAR>
 static void launch_conv_v(const float* in, const float* wp, const float* bias, float* out, int npatch,
                           int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
     const long rows = (long)npatch * 16;
-    dim3 grid((unsigned)((rows + BM - 1) / BM), cout / BN);
+    const long rtiles = (rows + BM - 1) / BM;
+    dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
     if (pool)
         conv3x3_relu_kernel<BN, SMALLC, true, VAR><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
     else

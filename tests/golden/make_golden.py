@@ -82,10 +82,10 @@ def main():
     np.savez(os.path.join(HERE, "tracking_head.npz"), feats_seed=13, X_rowsum=X.sum(axis=2), X_delim=X[:, :, 512],
              X_target=X[:, :, 513], logits=lg, offsets=offs, loss=loss, pred=pred)
 
-    # (4) VGG trunk on one 16x16 frame (weights from the seed)
+    # (4) VGG trunk on one 32x32 frame (weights from the seed; the HIP conv needs H, W multiples of 4 at conv4)
     rng = np.random.default_rng(17)
     ws = O.init_vgg_weights(rng)
-    frame = (rng.uniform(0, 255, size=(1, 16, 16, 3)).astype(np.float32) - O.VGG_MEAN)
+    frame = (rng.uniform(0, 255, size=(1, 32, 32, 3)).astype(np.float32) - O.VGG_MEAN)
     ws64 = {k: (w.astype(np.float64), b.astype(np.float64)) for k, (w, b) in ws.items()}
     f43 = O.vgg16_conv43(frame.astype(np.float64), ws64)
     f12 = O.maxpool2x2(O.vgg16_conv43(frame.astype(np.float64), ws64, upto="conv1_2"))
