@@ -24,6 +24,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+# HBM-side bytes of one VGG trunk pass over 640 frames (10 conv launches): rocprofv3 --pmc FETCH_SIZE (x2: gfx950
+# counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv.
+# Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
+TRUNK_TRAFFIC_BYTES_640_FRAMES = 5.4737e10 + 2.3121e10
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
@@ -223,7 +227,9 @@ def main():
                        "parallelism": "dp%d" % world, "mode": args.mode},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_relu_kernel (VGG trunk, 10 layers)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES * (B * T) / 640.0),
+                         "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
                          "algorithmic_flops_per_frame": conv_flops_per_frame()},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},
