@@ -155,7 +155,28 @@ int ntk_dnc_padded_dims(int N, int W, int R, int Wn, int hid, int O,
 int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value,
                     const float* xproj, const float* Wr, const float* Wi, const float* Wy,
                     float* mem, float* link, float* usage, float* rw, float* ww, float* prec,
-                    float* reads, float* hc, float* out, void* stream);
+                    float* reads, float* hc, float* out,
+                    /* per-step records for BPTT, all-or-none (null = inference): */
+                    float* rec_z, float* rec_gates, float* rec_c, float* rec_hc, float* rec_yin,
+                    float* rec_ifc, float* rec_u, float* rec_ww, float* rec_rw, float* rec_cw,
+                    float* rec_cr, float* rec_al, float* rec_p, float* rec_fwd, float* rec_bwd,
+                    float* rec_M, float* rec_L, float* rec_ypre, void* stream);
+
+/* Full BPTT through a recorded DNC sequence (num_writes == 1).  WrT [4*hid][ldkT], WiT [IP][ldhT]
+ * are transposed copies of Wr / Wi; *0 pointers are the state BEFORE step 0; gM [B,N,W] and
+ * gL [B,N,N] are zero-initialised scratch.  Out: raw gate gradients dgates [B,S,4*hid], raw
+ * interface gradients dxi [B,S,IP], gradient of the pre-clip output dypre [B,S,OP]; weight
+ * gradients follow as ntk_gemm_tn_f32 over the recorded rows. */
+int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value,
+                    const float* WrT, int ldkT, const float* WiT, int ldhT, const float* Wy,
+                    const float* mem0, const float* link0, const float* usage0, const float* rw0,
+                    const float* ww0, const float* prec0, const float* hc0,
+                    const float* rec_gates, const float* rec_c, const float* rec_ifc, const float* rec_u,
+                    const float* rec_ww, const float* rec_rw, const float* rec_cw, const float* rec_cr,
+                    const float* rec_al, const float* rec_p, const float* rec_fwd, const float* rec_bwd,
+                    const float* rec_M, const float* rec_L, const float* rec_ypre,
+                    const float* dout, float* gM, float* gL, float* dgates, float* dxi, float* dypre,
+                    void* stream);
 
 /* ------------------------------------------------------------------------
  * tracking head (direct_offset_output.py)

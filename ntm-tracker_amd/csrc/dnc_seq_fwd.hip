@@ -20,46 +20,13 @@
 // with "m before n" <=> u[m] < u[n] or (u[m] == u[n] and m < n): an O(N^2 / threads) product with
 // no sort and no permutation (the products are taken in index order, not sorted order: same
 // value up to fp32 rounding of a <=512-term product of numbers in [0,1]).
-#include "common.h"
+#include "dnc_common.h"
 
 // The reference evaluates usage / allocation as separate TF ops, each rounded to fp32; the allocation
 // SORTS usage, so which of two almost-equal slots wins can hinge on the last bit.  Keep the same
 // op-by-op rounding here (no fused multiply-add contraction) so ties and near-ties resolve as they do
 // in an op-by-op fp32 evaluation.
 #pragma clang fp contract(off)
-
-struct DncDims {
-    int B, S, N, W, R, Wn, hid, O;
-    int I, IP;       // interface width, padded
-    int K, ldz;      // R*W + hid, padded K+1
-    int ldh;         // padded hid+1
-    int Ky, ldy, OP; // hid + R*W, padded Ky+1, padded O
-    float clip;
-    // interface offsets
-    int oV, oE, oF, oAg, oWg, oRm, oKw, oBw, oKr, oBr;
-};
-
-static void dnc_fill_dims(DncDims& d, int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip) {
-    d.B = B; d.S = S; d.N = N; d.W = W; d.R = R; d.Wn = Wn; d.hid = hid; d.O = O; d.clip = clip;
-    d.oV = 0;
-    d.oE = d.oV + Wn * W;
-    d.oF = d.oE + Wn * W;
-    d.oAg = d.oF + R;
-    d.oWg = d.oAg + Wn;
-    d.oRm = d.oWg + Wn;
-    d.oKw = d.oRm + R * (1 + 2 * Wn);
-    d.oBw = d.oKw + Wn * W;
-    d.oKr = d.oBw + Wn;
-    d.oBr = d.oKr + R * W;
-    d.I = d.oBr + R;
-    d.IP = (d.I + 3) & ~3;
-    d.K = R * W + hid;
-    d.ldz = (d.K + 1 + 3) & ~3;
-    d.ldh = (hid + 1 + 3) & ~3;
-    d.Ky = hid + R * W;
-    d.ldy = (d.Ky + 1 + 3) & ~3;
-    d.OP = (O + 3) & ~3;
-}
 
 struct DncFwdArgs {
     DncDims d;
@@ -77,14 +44,30 @@ struct DncFwdArgs {
     float* reads;         // [B,R,W]    (access_output)
     float* hc;            // [B,2*hid]  (hidden then cell)
     float* out;           // [B,S,O]
+    // per-step records for BPTT (all nullable, all-or-none)
+    float* rec_z;         // [B,S,ldz]  [reads_prev ; h_prev ; 1 ; 0..]
+    float* rec_gates;     // [B,S,4*hid] activated gates (i, j, sigmoid(f+1), o per unit)
+    float* rec_c;         // [B,S,hid]  cell before clipping
+    float* rec_hc;        // [B,S,ldh]  [clipped h ; 1 ; 0..]
+    float* rec_yin;       // [B,S,ldy]  [clipped h ; reads_t ; 1 ; 0..]
+    float* rec_ifc;       // [B,S,IP]   activated interface
+    float* rec_u;         // [B,S,N]
+    float* rec_ww;        // [B,S,Wn,N]
+    float* rec_rw;        // [B,S,R,N]
+    float* rec_cw;        // [B,S,Wn,N]
+    float* rec_cr;        // [B,S,R,N]
+    float* rec_al;        // [B,S,Wn,N] allocation weights
+    float* rec_p;         // [B,S,Wn,N] precedence after the step
+    float* rec_fwd;       // [B,S,R,Wn,N]
+    float* rec_bwd;       // [B,S,R,Wn,N]
+    float* rec_M;         // [B,S,N,W]
+    float* rec_L;         // [B,S,Wn,N,N]
+    float* rec_ypre;      // [B,S,O]    output before clipping
 };
 
 struct DncLds {
     int part, Z, C, I, U, RW, WW, P, CW, CR, AL, FWD, BWD, SC, total;
 };
-
-constexpr int DT = 1024;      // threads per workgroup
-constexpr int DW = DT / 64;   // waves
 
 static void dnc_fwd_lds(const DncDims& d, DncLds& L) {
     const int nslG = DT / d.hid > 0 ? DT / d.hid : 1;
@@ -106,24 +89,6 @@ static void dnc_fwd_lds(const DncDims& d, DncLds& L) {
     L.FWD = take(d.R * d.Wn * d.N); L.BWD = take(d.R * d.Wn * d.N);
     L.SC = take(64);
     L.total = o;
-}
-
-__device__ __forceinline__ float dnc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float dnc_softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
-__device__ __forceinline__ float dnc_clip(float x, float c) { return c > 0.f ? fminf(fmaxf(x, -c), c) : x; }
-
-// in-place softmax of H rows of length N held in LDS; wave w owns rows w, w+DW, ... (no block barrier inside)
-__device__ __forceinline__ void lds_softmax_rows(float* v, int H, int N, int wave, int lane) {
-    for (int h = wave; h < H; h += DW) {
-        float* r = v + h * N;
-        float mx = -INFINITY;
-        for (int n = lane; n < N; n += 64) mx = fmaxf(mx, r[n]);
-        mx = wave_max(mx);
-        float s = 0.f;
-        for (int n = lane; n < N; n += 64) { const float e = expf(r[n] - mx); r[n] = e; s += e; }
-        s = wave_sum(s);
-        for (int n = lane; n < N; n += 64) r[n] = r[n] / s;
-    }
 }
 
 __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L) {
@@ -187,6 +152,8 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
         // ------------------------------------------------------------ P1: LSTM
         f32x4 xg = {0.f, 0.f, 0.f, 0.f};
         if (tid < hid) xg = reinterpret_cast<const f32x4*>(a.xproj)[bt * hid + tid] + Wr4[(size_t)K * hid + tid];
+        const bool rec = a.rec_z != nullptr;
+        if (rec) for (int i = tid; i < d.ldz; i += DT) a.rec_z[bt * d.ldz + i] = (i < K) ? sZ[i] : (i == K ? 1.f : 0.f);
         if (tid < nslG * hid) {
             const int j = tid % hid, ks = tid / hid;
             const int k0 = ks * kperG, k1 = min(K, k0 + kperG);
@@ -207,6 +174,15 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
             const float h2 = tanhf(c2) * go;
             sC[tid] = dnc_clip(c2, clipv);                          // dnc.py:112-113
             sZ[RWd + tid] = dnc_clip(h2, clipv);
+            if (rec) {
+                f32x4 ga = {gi, gj, gf, go};
+                reinterpret_cast<f32x4*>(a.rec_gates)[bt * hid + tid] = ga;
+                a.rec_c[bt * hid + tid] = c2;
+                a.rec_hc[bt * d.ldh + tid] = dnc_clip(h2, clipv);
+                a.rec_yin[bt * d.ldy + tid] = dnc_clip(h2, clipv);
+            }
+        } else if (rec && tid - hid < d.ldh - hid) {
+            a.rec_hc[bt * d.ldh + tid] = (tid == hid) ? 1.f : 0.f;
         }
         __syncthreads();
         // ------------------------------------------------------------ P2: interface
@@ -278,6 +254,11 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
         lds_softmax_rows(sCW, Wn, N, wave, lane);
         __syncthreads();
         // ------------------------------------------------------------ P5: allocation + write weights (access.py:220-257)
+        if (rec) {
+            for (int c = tid; c < IP; c += DT) a.rec_ifc[bt * IP + c] = sI[c];
+            for (int n = tid; n < N; n += DT) a.rec_u[bt * N + n] = sU[n];
+            for (int i = tid; i < Wn * N; i += DT) a.rec_cw[bt * Wn * N + i] = sCW[i];
+        }
         for (int j = 0; j < Wn; ++j) {
             if (tid < nslA * N) {
                 const int n = tid % N, sl = tid / N;
@@ -300,6 +281,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
                 float prod = 1.f;
                 for (int sl = 0; sl < nslA; ++sl) prod *= sPart[sl * N + n];
                 const float al = nun * prod;
+                if (rec) a.rec_al[(bt * Wn + j) * N + n] = al;
                 sWW[j * N + n] = wg * (ag * al + (1.0f - ag) * sCW[j * N + n]);
                 sAL[n] = sAL[n] + (1.0f - sAL[n]) * (ag * wg) * al;            // addressing.py:336-337
             }
@@ -322,6 +304,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
                     }
                     m = m * E + A;
                     reinterpret_cast<f32x4*>(gM + (size_t)n * W)[gl] = m;
+                    if (rec) reinterpret_cast<f32x4*>(a.rec_M + (bt * N + n) * W)[gl] = m;
                 }
                 float nsq = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3];
                 for (int o = LPR >> 1; o > 0; o >>= 1) nsq += __shfl_xor(nsq, o, 64);
@@ -371,6 +354,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
                             l[e] = v;
                         }
                         *reinterpret_cast<f32x4*>(Lj + (size_t)r * N + b0) = l;
+                        if (rec) *reinterpret_cast<f32x4*>(a.rec_L + ((bt * Wn + j) * N + r) * N + b0) = l;
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -417,10 +401,20 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
                 for (int j = 0; j < Wn; ++j)
                     v += rm[Wn + j] * sFWD[(i * Wn + j) * N + n] + rm[j] * sBWD[(i * Wn + j) * N + n];
                 sRW[idx] = v;
+                if (rec) a.rec_rw[bt * R * N + idx] = v;
             }
             for (int idx = tid; idx < Wn * N; idx += DT) {
                 const int j = idx / N;
-                sP[idx] = (1.0f - sSC[j]) * sP[idx] + sWW[idx];                  // addressing.py:238-240
+                const float pn = (1.0f - sSC[j]) * sP[idx] + sWW[idx];           // addressing.py:238-240
+                sP[idx] = pn;
+                if (rec) { a.rec_p[bt * Wn * N + idx] = pn; a.rec_ww[bt * Wn * N + idx] = sWW[idx]; }
+            }
+            if (rec) {
+                for (int idx = tid; idx < R * N; idx += DT) a.rec_cr[bt * R * N + idx] = sCR[idx];
+                for (int idx = tid; idx < R * Wn * N; idx += DT) {
+                    a.rec_fwd[bt * R * Wn * N + idx] = sFWD[idx];
+                    a.rec_bwd[bt * R * Wn * N + idx] = sBWD[idx];
+                }
             }
         }
         __syncthreads();
@@ -438,6 +432,9 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
             float s = 0.f;
             for (int sl = 0; sl < nslR; ++sl) s += sPart[sl * RWd + tid];
             sZ[tid] = s;
+            if (rec) a.rec_yin[bt * d.ldy + hid + tid] = s;
+        } else if (rec && tid >= RWd && tid < RWd + (d.ldy - d.Ky)) {
+            a.rec_yin[bt * d.ldy + d.Ky + (tid - RWd)] = (tid == RWd) ? 1.f : 0.f;
         }
         __syncthreads();
         for (int o = wave; o < d.O; o += DW) {                // y = clip([h ; reads] Wy + by)   (dnc.py:118-122)
@@ -447,7 +444,11 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
                 s += zv * a.Wy[(size_t)k * d.OP + o];
             }
             s = wave_sum(s);
-            if (lane == 0) a.out[bt * d.O + o] = dnc_clip(s + a.Wy[(size_t)d.Ky * d.OP + o], clipv);
+            if (lane == 0) {
+                const float pre = s + a.Wy[(size_t)d.Ky * d.OP + o];
+                a.out[bt * d.O + o] = dnc_clip(pre, clipv);
+                if (rec) a.rec_ypre[bt * d.O + o] = pre;
+            }
         }
         __syncthreads();
     }
@@ -481,7 +482,11 @@ extern "C" int ntk_dnc_padded_dims(int N, int W, int R, int Wn, int hid, int O,
 extern "C" int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value,
                                const float* xproj, const float* Wr, const float* Wi, const float* Wy,
                                float* mem, float* link, float* usage, float* rw, float* ww, float* prec,
-                               float* reads, float* hc, float* out, void* stream) {
+                               float* reads, float* hc, float* out,
+                               float* rec_z, float* rec_gates, float* rec_c, float* rec_hc, float* rec_yin,
+                               float* rec_ifc, float* rec_u, float* rec_ww, float* rec_rw, float* rec_cw,
+                               float* rec_cr, float* rec_al, float* rec_p, float* rec_fwd, float* rec_bwd,
+                               float* rec_M, float* rec_L, float* rec_ypre, void* stream) {
     DncFwdArgs a;
     dnc_fill_dims(a.d, B, S, N, W, R, Wn, hid, O, clip_value);
     NTK_REQUIRE(B > 0 && S > 0, NTK_ERR_BAD_SHAPE, "ntk_dnc_seq_fwd: B=%d S=%d", B, S);
@@ -496,6 +501,18 @@ extern "C" int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hi
                 NTK_ERR_BAD_PTR, "ntk_dnc_seq_fwd: xproj/Wr/Wi/mem/link must be 16-byte aligned");
     a.xproj = xproj; a.Wr = Wr; a.Wi = Wi; a.Wy = Wy; a.mem = mem; a.link = link; a.usage = usage; a.rw = rw; a.ww = ww;
     a.prec = prec; a.reads = reads; a.hc = hc; a.out = out;
+    {
+        float* recs[] = {rec_z, rec_gates, rec_c, rec_hc, rec_yin, rec_ifc, rec_u, rec_ww, rec_rw, rec_cw, rec_cr, rec_al,
+                         rec_p, rec_fwd, rec_bwd, rec_M, rec_L, rec_ypre};
+        int nn = 0;
+        for (float* r : recs) nn += (r != nullptr);
+        NTK_REQUIRE(nn == 0 || nn == 18, NTK_ERR_BAD_PTR, "ntk_dnc_seq_fwd: record pointers are all-or-none (%d of 18 given)", nn);
+        NTK_REQUIRE(nn == 0 || (ntk_aligned16(rec_gates) && ntk_aligned16(rec_M) && ntk_aligned16(rec_L)), NTK_ERR_BAD_PTR,
+                    "ntk_dnc_seq_fwd: rec_gates/rec_M/rec_L must be 16-byte aligned");
+    }
+    a.rec_z = rec_z; a.rec_gates = rec_gates; a.rec_c = rec_c; a.rec_hc = rec_hc; a.rec_yin = rec_yin; a.rec_ifc = rec_ifc;
+    a.rec_u = rec_u; a.rec_ww = rec_ww; a.rec_rw = rec_rw; a.rec_cw = rec_cw; a.rec_cr = rec_cr; a.rec_al = rec_al;
+    a.rec_p = rec_p; a.rec_fwd = rec_fwd; a.rec_bwd = rec_bwd; a.rec_M = rec_M; a.rec_L = rec_L; a.rec_ypre = rec_ypre;
     DncLds L;
     dnc_fwd_lds(a.d, L);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);

@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .ntm import gemm_nt
+from .ntm import gemm_nt, gemm_tn
 
 _P = _lib.ptr
 
@@ -122,7 +122,7 @@ class DNC(object):
         return (self.O,)
 
     # ---- sequence kernel: inputs time-major [S,B,D] like dynamic_rnn(time_major=True)
-    def run_sequence(self, inputs_tm, prev_state=None):
+    def run_sequence(self, inputs_tm, prev_state=None, record=False):
         S, B, D = inputs_tm.shape
         if self.D is None:
             self._build(D)
@@ -132,9 +132,19 @@ class DNC(object):
         X = torch.zeros((B, S, self.ldx), device=dev)
         X[:, :, :D] = inputs_tm.transpose(0, 1)
         xproj = gemm_nt(X.view(B * S, self.ldx), self.WxT)
-        return self.run_projected(xproj, B, S, prev_state)
+        self.last_X = X
+        return self.run_projected(xproj, B, S, prev_state, record=record)
 
-    def run_projected(self, xproj, B, S, prev_state=None):
+    REC_NAMES = ("z", "gates", "c", "hc", "yin", "ifc", "u", "ww", "rw", "cw", "cr", "al", "p", "fwd", "bwd", "M", "L", "ypre")
+
+    def _alloc_records(self, B, S):
+        e = lambda *s: torch.empty((B, S) + s, device=self.device)
+        N, W, R, Wn, hid = self.N, self.W, self.R, self.Wn, self.hid
+        return {"z": e(self.ldz), "gates": e(hid, 4), "c": e(hid), "hc": e(self.ldh), "yin": e(self.ldy), "ifc": e(self.IP),
+                "u": e(N), "ww": e(Wn, N), "rw": e(R, N), "cw": e(Wn, N), "cr": e(R, N), "al": e(Wn, N), "p": e(Wn, N),
+                "fwd": e(R, Wn, N), "bwd": e(R, Wn, N), "M": e(N, W), "L": e(Wn, N, N), "ypre": e(self.O)}
+
+    def run_projected(self, xproj, B, S, prev_state=None, record=False):
         """Sequence kernel on an already projected input (xproj [B*S, 4*hid] = X WxT^T)."""
         dev = self.device
         st = prev_state or self.initial_state(B)
@@ -145,13 +155,72 @@ class DNC(object):
         prec, reads = acc.linkage.precedence_weights.clone().contiguous(), st.access_output.clone().contiguous()
         hc = torch.cat([st.controller_state.hidden, st.controller_state.cell], dim=1).contiguous()
         out = torch.empty((B, S, self.O), device=dev)
+        rec = self._alloc_records(B, S) if record else {}
+        recp = [(_P(rec[k]) if record else None) for k in self.REC_NAMES]
         _lib.check(_lib.lib().ntk_dnc_seq_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value,
                                               _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
-                                              _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), _lib.stream()),
+                                              _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), *recp, _lib.stream()),
                    "ntk_dnc_seq_fwd")
+        self.last_record = rec
+        self.last_initial = st
         new = DNCState(reads, AccessState(mem, rw, ww, TemporalLinkageState(link, prec), usage),
                        LSTMState(hc[:, :self.hid].contiguous(), hc[:, self.hid:].contiguous()))
         return out.transpose(0, 1), new          # time-major [S,B,O]
+
+    def backward_sequence(self, X, dout):
+        """BPTT through the last recorded sequence (run_projected(..., record=True)).
+        X [B,S,ldx] serialised inputs, dout [B,S,O] = d loss / d output.  Returns the gradients in the
+        reference's Sonnet variable layout ({name: tensor on device})."""
+        if self.Wn != 1:
+            raise _lib.NtkError("DNC BPTT on the HIP path implements num_writes == 1 (got %d)" % self.Wn)
+        rec, st0 = self.last_record, self.last_initial
+        if not rec:
+            raise _lib.NtkError("backward_sequence needs a recorded forward pass (record=True)")
+        B, S, _ = X.shape
+        dev, L, stream = self.device, _lib.lib(), _lib.stream()
+        hid = self.hid
+        ldkT, ldhT = (self.K + 3) // 4 * 4, (hid + 3) // 4 * 4
+        WrT = torch.empty((4 * hid, ldkT), device=dev)
+        WiT = torch.empty((self.IP, ldhT), device=dev)
+        _lib.check(L.ntk_transpose_pad(_P(self.Wr), 4 * hid, _P(WrT), ldkT, self.K, 4 * hid, stream), "ntk_transpose_pad")
+        _lib.check(L.ntk_transpose_pad(_P(self.Wi), self.IP, _P(WiT), ldhT, hid, self.IP, stream), "ntk_transpose_pad")
+        acc = st0.access_state
+        hc0 = torch.cat([st0.controller_state.hidden, st0.controller_state.cell], dim=1).contiguous()
+        gM = torch.zeros((B, self.N, self.W), device=dev)
+        gL = torch.zeros((B, self.N, self.N), device=dev)
+        dgates = torch.empty((B, S, 4 * hid), device=dev)
+        dxi = torch.empty((B, S, self.IP), device=dev)
+        dypre = torch.empty((B, S, self.OP), device=dev)
+        c = lambda t: _P(t.contiguous())
+        _lib.check(L.ntk_dnc_seq_bwd(
+            B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value,
+            _P(WrT), ldkT, _P(WiT), ldhT, _P(self.Wy),
+            c(acc.memory), c(acc.linkage.link), c(acc.usage), c(acc.read_weights), c(acc.write_weights),
+            c(acc.linkage.precedence_weights), _P(hc0),
+            _P(rec["gates"]), _P(rec["c"]), _P(rec["ifc"]), _P(rec["u"]), _P(rec["ww"]), _P(rec["rw"]), _P(rec["cw"]),
+            _P(rec["cr"]), _P(rec["al"]), _P(rec["p"]), _P(rec["fwd"]), _P(rec["bwd"]), _P(rec["M"]), _P(rec["L"]),
+            _P(rec["ypre"]), c(dout), _P(gM), _P(gL), _P(dgates), _P(dxi), _P(dypre), stream), "ntk_dnc_seq_bwd")
+        BS = B * S
+        gWxT, gWr = torch.empty_like(self.WxT), torch.empty_like(self.Wr)
+        gWi, gWy = torch.empty_like(self.Wi), torch.empty_like(self.Wy)
+        gemm_tn(dgates.view(BS, 4 * hid), X.view(BS, self.ldx), gWxT)
+        gemm_tn(rec["z"].view(BS, self.ldz), dgates.view(BS, 4 * hid), gWr)
+        gemm_tn(rec["hc"].view(BS, self.ldh), dxi.view(BS, self.IP), gWi)
+        gemm_tn(rec["yin"].view(BS, self.ldy), dypre.view(BS, self.OP), gWy)
+        self.packed_grads = {"WxT": gWxT, "Wr": gWr, "Wi": gWi, "Wy": gWy}
+        # unpack to the Sonnet layout
+        inv = torch.arange(4 * hid, device=dev).view(hid, 4).t().reshape(-1)
+        Wg = torch.cat([gWxT[:, :self.D].t(), gWr[:self.K]], dim=0)
+        out = {"lstm/w_gates": Wg[:, inv].contiguous(), "lstm/b_gates": gWr[self.K][inv].contiguous()}
+        o = 0
+        for name in INTERFACE:
+            wd = self.interface_widths()[name]
+            out["memory_access/%s/w" % name] = gWi[:hid, o:o + wd].contiguous()
+            out["memory_access/%s/b" % name] = gWi[hid, o:o + wd].contiguous()
+            o += wd
+        out["output_linear/w"] = gWy[:self.Ky, :self.O].contiguous()
+        out["output_linear/b"] = gWy[self.Ky, :self.O].contiguous()
+        return out
 
     def __call__(self, inputs, prev_state):
         """One step of the core: (output [B,O], DNCState), dnc.py:84-127."""

@@ -138,3 +138,65 @@ def test_dnc_offset_tracker_pipeline(cuda):
     offs = torch.zeros((B, T, 2), device=cuda)
     _l, pred, _ = tracker.offset_loss(logits, offs, T, want_grad=False)
     np.testing.assert_allclose(pred.cpu().numpy(), pred_ref, atol=5e-5)
+
+
+BWD_CASES = [
+    # name, D, O, N, W, R, hid, clip, S, B, zero initial state?
+    ("small_random_state", 10, 3, 16, 8, 2, 16, 20.0, 5, 2, False),
+    ("small_zero_state", 12, 2, 32, 12, 3, 24, 20.0, 6, 2, True),
+    ("tight_clip", 10, 2, 16, 8, 2, 16, 0.4, 4, 2, False),
+    ("c3_shape", 514, 2, 256, 64, 4, 200, 20.0, 4, 1, False),
+]
+
+
+@pytest.mark.parametrize("name,Din,O,N,W,R,hid,clip,S,B,zero", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, hid, clip, S, B, zero):
+    """d(sum(y * G)) / d(params) through S recorded steps vs torch-autograd on the float64 restatement.
+    Inputs are chosen without near-tied usages (see _random_state) so the allocation sort is well conditioned."""
+    from oracle import dnc_oracle_torch as DT
+    from ntmtrack import dnc as G
+    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=1, hidden_size=hid, clip_value=clip)
+    rng = np.random.default_rng(17)
+    p = D.init_params(cfg, rng)
+    for k in p:
+        if k.endswith("/b") or k.endswith("b_gates"):
+            p[k] = rng.uniform(-0.3, 0.3, size=p[k].shape).astype(np.float32)
+        if k.startswith("memory_access/") and k.endswith("/w"):
+            p[k] = (p[k] * 4).astype(np.float32)
+    x = rng.standard_normal((S, B, Din)).astype(np.float32)
+    Gy = rng.standard_normal((S, B, O)).astype(np.float32)
+    st0 = None if zero else _random_state(cfg, B, rng)
+
+    # oracle (float64 autograd)
+    t64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
+    pt = {k: t64(v).requires_grad_(True) for k, v in p.items()}
+    ost = None
+    if st0 is not None:
+        a0 = st0.access_state
+        ost = DT.DNCState(t64(st0.access_output), DT.AccessState(t64(a0.memory), t64(a0.read_weights), t64(a0.write_weights),
+                          DT.TemporalLinkageState(t64(a0.linkage.link), t64(a0.linkage.precedence_weights)), t64(a0.usage)),
+                          DT.LSTMState(t64(st0.controller_state.hidden), t64(st0.controller_state.cell)))
+    ys, _ = DT.run_model(cfg, pt, t64(x), ost)
+    (ys * t64(Gy)).sum().backward()
+
+    core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, clip, device=cuda)
+    core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    gst = None
+    if st0 is not None:
+        t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(cuda)
+        a0 = st0.access_state
+        gst = G.DNCState(t(st0.access_output), G.AccessState(t(a0.memory), t(a0.read_weights), t(a0.write_weights),
+                         G.TemporalLinkageState(t(a0.linkage.link), t(a0.linkage.precedence_weights)), t(a0.usage)),
+                         G.LSTMState(t(st0.controller_state.hidden), t(st0.controller_state.cell)))
+    out, _st = core.run_sequence(torch.from_numpy(x).to(cuda), gst, record=True)
+    np.testing.assert_allclose(out.cpu().numpy(), ys.detach().numpy(), atol=5e-5)
+    dout = torch.from_numpy(np.ascontiguousarray(np.transpose(Gy, (1, 0, 2)))).to(cuda)      # [B,S,O]
+    grads = core.backward_sequence(core.last_X, dout)
+    torch.cuda.synchronize()
+    worst = {}
+    for k in sorted(p):
+        ref = pt[k].grad.numpy()
+        got = grads[k].cpu().numpy()
+        worst[k] = float(np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) + 1e-30))
+    bad = {k: v for k, v in worst.items() if v > 3e-3}
+    assert not bad, bad
