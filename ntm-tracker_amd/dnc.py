@@ -28,6 +28,28 @@ INTERFACE = ("write_vectors", "erase_vectors", "free_gate", "allocation_gate", "
              "write_keys", "write_strengths", "read_keys", "read_strengths")
 
 
+class FlatParams(object):
+    """Flat fp32 parameter buffer with named 16-byte-aligned views and a same-shaped gradient."""
+
+    def __init__(self, shapes, device):
+        n = 0
+        self.offsets = {}
+        for name, shp in shapes:
+            sz = 1
+            for s_ in shp:
+                sz *= s_
+            n = (n + 3) // 4 * 4
+            self.offsets[name] = (n, sz, shp)
+            n += sz
+        self.numel = (n + 3) // 4 * 4
+        self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
+
+    def view(self, name, grad=False):
+        o, sz, shp = self.offsets[name]
+        return (self.grad if grad else self.flat)[o:o + sz].view(shp)
+
+
 class DNC(object):
     def __init__(self, access_config, controller_config, output_size, clip_value=None, input_dim=None,
                  device="cuda", seed=0):
@@ -95,11 +117,37 @@ class DNC(object):
         Wy = torch.zeros((self.ldy, self.OP))
         Wy[:self.Ky, :self.O] = t(sd["output_linear/w"])
         Wy[self.Ky, :self.O] = t(sd["output_linear/b"])
-        self.WxT, self.Wr, self.Wi, self.Wy = WxT.to(dev), Wr.to(dev), Wi.to(dev), Wy.to(dev)
-        self._sd = {k: t(v).clone() for k, v in sd.items()}
+        # flat fp32 master copy (kernel layout) + same-shaped gradient: the optimiser and the all-reduce are flat passes
+        shapes = [("WxT", WxT), ("Wr", Wr), ("Wi", Wi), ("Wy", Wy)]
+        self.params = FlatParams([(n, tuple(v.shape)) for n, v in shapes], dev)
+        for n, v in shapes:
+            self.params.view(n).copy_(v.to(dev))
+
+    WxT = property(lambda self: self.params.view("WxT"))
+    Wr = property(lambda self: self.params.view("Wr"))
+    Wi = property(lambda self: self.params.view("Wi"))
+    Wy = property(lambda self: self.params.view("Wy"))
+
+    def _unpack(self, grad=False):
+        """Packed kernel layout -> the reference's Sonnet variable layout (device tensors)."""
+        hid, dev = self.hid, self.device
+        gWxT, gWr = self.params.view("WxT", grad), self.params.view("Wr", grad)
+        gWi, gWy = self.params.view("Wi", grad), self.params.view("Wy", grad)
+        inv = torch.arange(4 * hid, device=dev).view(hid, 4).t().reshape(-1)
+        Wg = torch.cat([gWxT[:, :self.D].t(), gWr[:self.K]], dim=0)
+        out = {"lstm/w_gates": Wg[:, inv].contiguous(), "lstm/b_gates": gWr[self.K][inv].contiguous()}
+        o = 0
+        for name in INTERFACE:
+            wd = self.interface_widths()[name]
+            out["memory_access/%s/w" % name] = gWi[:hid, o:o + wd].contiguous()
+            out["memory_access/%s/b" % name] = gWi[hid, o:o + wd].contiguous()
+            o += wd
+        out["output_linear/w"] = gWy[:self.Ky, :self.O].contiguous()
+        out["output_linear/b"] = gWy[self.Ky, :self.O].contiguous()
+        return out
 
     def state_dict(self):
-        return {k: v.clone() for k, v in self._sd.items()}
+        return {k: v.cpu() for k, v in self._unpack().items()}
 
     # ---- state
     def initial_state(self, batch_size, dtype=torch.float32):
@@ -201,26 +249,12 @@ class DNC(object):
             _P(rec["cr"]), _P(rec["al"]), _P(rec["p"]), _P(rec["fwd"]), _P(rec["bwd"]), _P(rec["M"]), _P(rec["L"]),
             _P(rec["ypre"]), c(dout), _P(gM), _P(gL), _P(dgates), _P(dxi), _P(dypre), stream), "ntk_dnc_seq_bwd")
         BS = B * S
-        gWxT, gWr = torch.empty_like(self.WxT), torch.empty_like(self.Wr)
-        gWi, gWy = torch.empty_like(self.Wi), torch.empty_like(self.Wy)
-        gemm_tn(dgates.view(BS, 4 * hid), X.view(BS, self.ldx), gWxT)
-        gemm_tn(rec["z"].view(BS, self.ldz), dgates.view(BS, 4 * hid), gWr)
-        gemm_tn(rec["hc"].view(BS, self.ldh), dxi.view(BS, self.IP), gWi)
-        gemm_tn(rec["yin"].view(BS, self.ldy), dypre.view(BS, self.OP), gWy)
-        self.packed_grads = {"WxT": gWxT, "Wr": gWr, "Wi": gWi, "Wy": gWy}
-        # unpack to the Sonnet layout
-        inv = torch.arange(4 * hid, device=dev).view(hid, 4).t().reshape(-1)
-        Wg = torch.cat([gWxT[:, :self.D].t(), gWr[:self.K]], dim=0)
-        out = {"lstm/w_gates": Wg[:, inv].contiguous(), "lstm/b_gates": gWr[self.K][inv].contiguous()}
-        o = 0
-        for name in INTERFACE:
-            wd = self.interface_widths()[name]
-            out["memory_access/%s/w" % name] = gWi[:hid, o:o + wd].contiguous()
-            out["memory_access/%s/b" % name] = gWi[hid, o:o + wd].contiguous()
-            o += wd
-        out["output_linear/w"] = gWy[:self.Ky, :self.O].contiguous()
-        out["output_linear/b"] = gWy[self.Ky, :self.O].contiguous()
-        return out
+        P = self.params
+        gemm_tn(dgates.view(BS, 4 * hid), X.view(BS, self.ldx), P.view("WxT", grad=True))
+        gemm_tn(rec["z"].view(BS, self.ldz), dgates.view(BS, 4 * hid), P.view("Wr", grad=True))
+        gemm_tn(rec["hc"].view(BS, self.ldh), dxi.view(BS, self.IP), P.view("Wi", grad=True))
+        gemm_tn(rec["yin"].view(BS, self.ldy), dypre.view(BS, self.OP), P.view("Wy", grad=True))
+        return self._unpack(grad=True)
 
     def __call__(self, inputs, prev_state):
         """One step of the core: (output [B,O], DNCState), dnc.py:84-127."""

@@ -187,7 +187,7 @@ class DNCOffsetTracker(object):
 
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  read_head_size=4, write_head_size=1, clip_value=20, feature_channels=512, device="cuda", seed=42,
-                 vgg_chunk_frames=1024):
+                 vgg_chunk_frames=1024, learning_rate=1e-4, optimizer_epsilon=1e-10, max_gradient_norm=50.0):
         from .dnc import DNC
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
@@ -196,13 +196,32 @@ class DNCOffsetTracker(object):
         self.core = DNC({"memory_size": mem_size, "word_size": mem_dim, "num_reads": read_head_size,
                          "num_writes": write_head_size}, {"hidden_size": hidden_size}, 2, clip_value,
                         input_dim=feature_channels + 2, device=self.device, seed=seed)
+        # _with_dnc.py:615-620: clip_by_global_norm(50), RMSPropOptimizer(lr, epsilon=1e-10) -> decay 0.9, momentum 0
+        self.opt = RMSPropClip(self.core.params, learning_rate, 0.9, 0.0, optimizer_epsilon, max_gradient_norm)
 
-    def forward_features(self, fmap, gts0):
+    def forward_features(self, fmap, gts0, record=False):
         """-> logits [B,S,2] (batch-major view of the time-major core output, _with_dnc.py:534-541)."""
+        from .ntm import gemm_nt
         X = gather_serialize(fmap, gts0, self.B, self.T, self.core.ldx)
-        xproj = __import__("ntmtrack.ntm", fromlist=["gemm_nt"]).gemm_nt(X.view(self.B * self.S, self.core.ldx), self.core.WxT)
-        out_tm, state = self.core.run_projected(xproj, self.B, self.S)
+        xproj = gemm_nt(X.view(self.B * self.S, self.core.ldx), self.core.WxT)
+        out_tm, state = self.core.run_projected(xproj, self.B, self.S, record=record)
+        self._X = X
         return out_tm.transpose(0, 1).contiguous(), state
+
+    def loss_and_grads(self, fmap, gts0, offsets):
+        logits, _state = self.forward_features(fmap, gts0, record=True)
+        loss, pred, dlogits = offset_loss(logits, offsets, self.T)
+        self.core.backward_sequence(self._X, dlogits)
+        return loss, pred
+
+    def train_step(self, frames, gts0, offsets):
+        """VGG forward, DNC forward + BPTT, gradient all-reduce (if distributed), clip(50) + RMSProp."""
+        if self.vgg is None:
+            raise _lib.NtkError("tracker was built without VGG weights")
+        loss, _ = self.loss_and_grads(self.vgg(frames), gts0, offsets)
+        parallel.allreduce_gradients(self.core.params.grad)
+        self.opt.step()
+        return loss
 
     def infer(self, frames, gts0):
         if self.vgg is None:

@@ -200,3 +200,41 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, h
         worst[k] = float(np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) + 1e-30))
     bad = {k: v for k, v in worst.items() if v > 3e-3}
     assert not bad, bad
+
+
+def test_dnc_offset_tracker_training_step(cuda):
+    """One optimiser step of the DNC tracker head (no VGG): loss and the clipped TF-RMSProp update equal the
+    oracle chain (torch-autograd gradients -> clip_by_global_norm(50) -> RMSProp(decay .9, momentum 0, eps 1e-10))."""
+    from oracle import ntm_oracle as O
+    from oracle import dnc_oracle_torch as DT
+    from ntmtrack import tracker
+    B, T = 2, 2
+    rng = np.random.default_rng(8)
+    trk = tracker.DNCOffsetTracker(B, T, vgg_weights=None, mem_size=32, mem_dim=16, hidden_size=32, read_head_size=2,
+                                   write_head_size=1, clip_value=20, device=cuda, seed=11)
+    sd = {k: v.numpy() for k, v in trk.core.state_dict().items()}
+    cfg = D.DNCConfig(514, 2, memory_size=32, word_size=16, num_reads=2, num_writes=1, hidden_size=32, clip_value=20)
+    fmap = np.maximum(rng.standard_normal((B * T, 28, 28, 512)), 0).astype(np.float32)
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    offs = rng.uniform(-.5, .5, size=(B, T, 2)).astype(np.float32)
+    x = O.serialize_inputs(O.extract_features(fmap).reshape(B, T, 64, 512), gts)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    ys, _ = DT.run_model(cfg, pt, torch.tensor(np.ascontiguousarray(np.transpose(x, (1, 0, 2))), dtype=torch.float64))
+    logits = ys.permute(1, 0, 2)
+    from oracle import ntm_oracle_torch as OT
+    loss_ref, _ = OT.offset_loss(logits, torch.tensor(offs, dtype=torch.float64))
+    loss_ref.backward()
+    names = sorted(sd)
+    clipped, gn = O.clip_by_global_norm([pt[k].grad.numpy() for k in names], 50.0)
+    loss, _ = trk.loss_and_grads(torch.from_numpy(fmap).to(cuda), torch.from_numpy(gts[:, 0].copy()).to(cuda),
+                                 torch.from_numpy(offs).to(cuda))
+    trk.opt.step()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), float(loss_ref.detach()), rtol=1e-4)
+    np.testing.assert_allclose(float(trk.opt.gnorm.cpu()), gn, rtol=3e-3)
+    new = trk.core.state_dict()
+    for k, g in zip(names, clipped):
+        ref_new, _, _ = O.rmsprop_step(sd[k].astype(np.float64), g, np.ones_like(g), np.zeros_like(g), lr=1e-4, decay=0.9, momentum=0.0, eps=1e-10)
+        step = np.max(np.abs(ref_new - sd[k]))
+        err = np.max(np.abs(new[k].numpy().astype(np.float64) - ref_new))
+        assert err <= 6e-8 + 5e-3 * step, (k, err, step)
