@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--seq-len", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--model", default="ntm", choices=["ntm", "dnc"],
+                    help="ntm = BASELINE configs[1] (the headline metric); dnc = configs[2] (DNC 256x64, 4 read heads), reported for reference")
+    ap.add_argument("--mem-size", type=int, default=None)
+    ap.add_argument("--mem-dim", type=int, default=None)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,7 +141,12 @@ def main():
 
     B, T = args.batch, args.seq_len
     ws = vgg_weights(42)
-    trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42)   # same init on every rank
+    if args.model == "dnc":
+        trk = tracker.DNCOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, mem_size=args.mem_size or 256,
+                                       mem_dim=args.mem_dim or 64)
+        trk.add_pipeline()
+    else:
+        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42)   # same init on every rank
     log("tracker built; generating synthetic inputs")
     frames, gts0, offs = synth_inputs(B, T, dev, 42 + rank)
     log("inputs resident in HBM: frames %s" % (tuple(frames.shape),))
@@ -215,14 +224,18 @@ def main():
         flops = conv_flops_per_frame() * B * T
         achieved = flops / (vgg_ms * 1e-3) / 1e12
         out = {
-            "metric": "frames/sec (whole node) VGG16+NTM(128x20) seq_len=%d" % T,
+            "metric": ("frames/sec (whole node) VGG16+NTM(128x20) seq_len=%d" % T) if args.model == "ntm" else
+                      ("frames/sec (whole node) VGG16+DNC(%dx%d) seq_len=%d" % (trk.core.N, trk.core.W, T)),
             "value": round(frames_total / elapsed, 2), "unit": "frames/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: VGG-16 conv1_1..conv4_3 + NTMCell(128x20, hidden 200, R4/W1) "
-                                   "direct_offset_output %s step, batch %d sequences/GPU, seq_len %d, 224x224 frames"
-                                   % ("training" if args.mode == "train" else "inference", B, T),
+            "config": {"workload": ("BASELINE configs[1]: VGG-16 conv1_1..conv4_3 + NTMCell(128x20, hidden 200, R4/W1) "
+                                    "direct_offset_output %s step, batch %d sequences/GPU, seq_len %d, 224x224 frames"
+                                    % ("training" if args.mode == "train" else "inference", B, T)) if args.model == "ntm" else
+                                   ("BASELINE configs[2]: VGG-16 conv1_1..conv4_3 + DNC core (mem %dx%d, 4 read heads, hidden 200, clip 20) "
+                                    "direct_offset_output_with_dnc %s step, batch %d sequences/GPU, seq_len %d"
+                                    % (trk.core.N, trk.core.W, "training" if args.mode == "train" else "inference", B, T)),
                        "global_batch": world * B, "seq_len": T, "steps_per_sequence": T * 65,
                        "parallelism": "dp%d" % world, "mode": args.mode},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_relu_kernel (VGG trunk, 10 layers)",

@@ -68,7 +68,66 @@ class RMSPropClip(object):
         self.global_step += 1
 
 
-class NTMOffsetTracker(object):
+class _TwoStreamPipeline(object):
+    """Two-stage software pipeline shared by the trackers: the frozen VGG trunk of batch i+1 runs on its own
+    HIP stream while the recurrent core's forward / BPTT / optimiser of batch i runs on a high-priority stream."""
+
+    def add_pipeline(self):
+        self._s_vgg = None
+        self._s_ntm = None
+        self._slots = []
+        self._pending = []
+
+    def _streams(self):
+        if self._s_vgg is None:
+            self._s_vgg = torch.cuda.Stream(device=self.device)
+            self._s_ntm = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._s_vgg, self._s_ntm
+
+    def submit_features(self, frames):
+        """Enqueue the VGG trunk for `frames` on the feature stream (returns immediately).
+        At most two submissions may be outstanding."""
+        s_vgg, _ = self._streams()
+        if len(self._pending) >= 2:
+            raise _lib.NtkError("submit_features: two feature batches already outstanding")
+        F = frames.shape[0]
+        if not self._slots:
+            self._slots = [dict(buf=torch.empty((F, frames.shape[1] // 8, frames.shape[2] // 8, 512), device=self.device),
+                                free=None) for _ in range(2)]
+        busy = [id(p[0]) for p in self._pending]
+        slot = next(sl for sl in self._slots if id(sl) not in busy)
+        s_vgg.wait_stream(torch.cuda.current_stream(self.device))       # frames were produced on the caller's stream
+        if slot["free"] is not None:
+            s_vgg.wait_event(slot["free"])                               # core pass that last read this buffer is done
+        with torch.cuda.stream(s_vgg):
+            self.vgg(frames, out=slot["buf"])
+            done = torch.cuda.Event()
+            done.record(s_vgg)
+        self._pending.append((slot, done))
+
+    def train_on_submitted(self, gts0, offsets):
+        """Core forward + BPTT + (all-reduce) + optimiser on the oldest submitted feature batch."""
+        _, s_ntm = self._streams()
+        slot, done = self._pending.pop(0)
+        s_ntm.wait_stream(torch.cuda.current_stream(self.device))
+        s_ntm.wait_event(done)
+        with torch.cuda.stream(s_ntm):
+            loss, _pred = self.loss_and_grads(slot["buf"], gts0, offsets)
+            parallel.allreduce_gradients(self._flat_grad())
+            self.opt.step()
+            slot["free"] = torch.cuda.Event()
+            slot["free"].record(s_ntm)
+        return loss
+
+    def join(self):
+        """Make the caller's stream wait for everything enqueued on the pipeline streams."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._s_vgg is not None:
+            cur.wait_stream(self._s_vgg)
+            cur.wait_stream(self._s_ntm)
+
+
+class NTMOffsetTracker(_TwoStreamPipeline):
     """VGG-16 conv4_3 + NTMCell offsets tracker, defaults from direct_offset_output.py:21-42."""
 
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
@@ -84,12 +143,7 @@ class NTMOffsetTracker(object):
                             read_head_size=read_head_size, write_first=write_first,
                             input_dim=feature_channels + 2, device=self.device, init_scale=init_scale, seed=seed)
         self.opt = RMSPropClip(self.cell.params, learning_rate, decay, momentum, 1e-10, max_gradient_norm)
-        # two-stage software pipeline: the frozen VGG trunk of batch i+1 runs on its own HIP stream
-        # while the NTM forward/BPTT/optimiser of batch i runs on a high-priority stream
-        self._s_vgg = None
-        self._s_ntm = None
-        self._slots = []
-        self._pending = []
+        self.add_pipeline()
 
     # ---- forward pieces
     def features(self, frames):
@@ -121,54 +175,8 @@ class NTMOffsetTracker(object):
         self.cell.init_state_backward(g0, self.B)
         return loss, pred
 
-    # ---- pipelined training: VGG(i+1) overlaps NTM(i)
-    def _streams(self):
-        if self._s_vgg is None:
-            self._s_vgg = torch.cuda.Stream(device=self.device)
-            self._s_ntm = torch.cuda.Stream(device=self.device, priority=-1)
-        return self._s_vgg, self._s_ntm
-
-    def submit_features(self, frames):
-        """Enqueue the VGG trunk for `frames` on the feature stream (returns immediately).
-        At most two submissions may be outstanding."""
-        s_vgg, _ = self._streams()
-        if len(self._pending) >= 2:
-            raise _lib.NtkError("submit_features: two feature batches already outstanding")
-        F = frames.shape[0]
-        if not self._slots:
-            self._slots = [dict(buf=torch.empty((F, frames.shape[1] // 8, frames.shape[2] // 8, 512), device=self.device),
-                                free=None) for _ in range(2)]
-        busy = [id(p[0]) for p in self._pending]
-        slot = next(sl for sl in self._slots if id(sl) not in busy)
-        s_vgg.wait_stream(torch.cuda.current_stream(self.device))       # frames were produced on the caller's stream
-        if slot["free"] is not None:
-            s_vgg.wait_event(slot["free"])                               # NTM pass that last read this buffer is done
-        with torch.cuda.stream(s_vgg):
-            self.vgg(frames, out=slot["buf"])
-            done = torch.cuda.Event()
-            done.record(s_vgg)
-        self._pending.append((slot, done))
-
-    def train_on_submitted(self, gts0, offsets):
-        """NTM forward + BPTT + (all-reduce) + optimiser on the oldest submitted feature batch."""
-        _, s_ntm = self._streams()
-        slot, done = self._pending.pop(0)
-        s_ntm.wait_stream(torch.cuda.current_stream(self.device))
-        s_ntm.wait_event(done)
-        with torch.cuda.stream(s_ntm):
-            loss, _pred = self.loss_and_grads(slot["buf"], gts0, offsets)
-            parallel.allreduce_gradients(self.cell.params.grad)
-            self.opt.step()
-            slot["free"] = torch.cuda.Event()
-            slot["free"].record(s_ntm)
-        return loss
-
-    def join(self):
-        """Make the caller's stream wait for everything enqueued on the pipeline streams."""
-        cur = torch.cuda.current_stream(self.device)
-        if self._s_vgg is not None:
-            cur.wait_stream(self._s_vgg)
-            cur.wait_stream(self._s_ntm)
+    def _flat_grad(self):
+        return self.cell.params.grad
 
     def train_step(self, frames, gts0, offsets):
         """VGG forward, NTM forward + BPTT, gradient all-reduce (if distributed), clip + RMSProp.
@@ -180,7 +188,7 @@ class NTMOffsetTracker(object):
         return loss
 
 
-class DNCOffsetTracker(object):
+class DNCOffsetTracker(_TwoStreamPipeline):
     """VGG-16 conv4_3 + DNC core offsets tracker (direct_offset_output_with_dnc.py:408-648), forward path:
     frames -> VGG -> 64-point gather + serialise -> time-major dynamic_rnn over dnc.DNC (clip_value 20)
     -> output gather at the delimiter steps -> tanh.  Defaults from :22-43 (mem 128x20, R4/W1, hidden 200)."""
@@ -198,6 +206,10 @@ class DNCOffsetTracker(object):
                         input_dim=feature_channels + 2, device=self.device, seed=seed)
         # _with_dnc.py:615-620: clip_by_global_norm(50), RMSPropOptimizer(lr, epsilon=1e-10) -> decay 0.9, momentum 0
         self.opt = RMSPropClip(self.core.params, learning_rate, 0.9, 0.0, optimizer_epsilon, max_gradient_norm)
+        self.add_pipeline()
+
+    def _flat_grad(self):
+        return self.core.params.grad
 
     def forward_features(self, fmap, gts0, record=False):
         """-> logits [B,S,2] (batch-major view of the time-major core output, _with_dnc.py:534-541)."""
