@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--model", default="ntm", choices=["ntm", "dnc"],
                     help="ntm = BASELINE configs[1] (the headline metric); dnc = configs[2] (DNC 256x64, 4 read heads), reported for reference")
+    ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = exact fp32 MFMA (configs 2-4, the headline); bf16 = bf16 operands / fp32 accumulate (config 5)")
     ap.add_argument("--mem-size", type=int, default=None)
     ap.add_argument("--mem-dim", type=int, default=None)
     args = ap.parse_args()
@@ -143,10 +145,9 @@ def main():
     ws = vgg_weights(42)
     if args.model == "dnc":
         trk = tracker.DNCOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, mem_size=args.mem_size or 256,
-                                       mem_dim=args.mem_dim or 64)
-        trk.add_pipeline()
+                                       mem_dim=args.mem_dim or 64, conv_dtype=args.conv_dtype)
     else:
-        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42)   # same init on every rank
+        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, conv_dtype=args.conv_dtype)   # same init on every rank
     log("tracker built; generating synthetic inputs")
     frames, gts0, offs = synth_inputs(B, T, dev, 42 + rank)
     log("inputs resident in HBM: frames %s" % (tuple(frames.shape),))
@@ -223,13 +224,16 @@ def main():
         ntm_ms = float(np.mean([a.elapsed_time(b) for a, b in marks_ntm])) if marks_ntm else 0.0
         flops = conv_flops_per_frame() * B * T
         achieved = flops / (vgg_ms * 1e-3) / 1e12
+        PEAK = FP32_MFMA_PEAK_TFLOPS if args.conv_dtype == "f32" else 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
         out = {
             "metric": ("frames/sec (whole node) VGG16+NTM(128x20) seq_len=%d" % T) if args.model == "ntm" else
                       ("frames/sec (whole node) VGG16+DNC(%dx%d) seq_len=%d" % (trk.core.N, trk.core.W, T)),
             "value": round(frames_total / elapsed, 2), "unit": "frames/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.conv_dtype == "f32" else "bf16 conv operands / f32 accumulate, f32 memory cell",
+            "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: VGG-16 conv1_1..conv4_3 + NTMCell(128x20, hidden 200, R4/W1) "
                                     "direct_offset_output %s step, batch %d sequences/GPU, seq_len %d, 224x224 frames"
                                     % ("training" if args.mode == "train" else "inference", B, T)) if args.model == "ntm" else
@@ -238,10 +242,11 @@ def main():
                                     % (trk.core.N, trk.core.W, "training" if args.mode == "train" else "inference", B, T)),
                        "global_batch": world * B, "seq_len": T, "steps_per_sequence": T * 65,
                        "parallelism": "dp%d" % world, "mode": args.mode},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_relu_kernel (VGG trunk, 10 layers)",
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES * (B * T) / 640.0),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_relu_kernel (VGG trunk, 10 layers)" if args.conv_dtype == "f32"
+                         else "conv3x3_relu_bf16_kernel (VGG trunk, 10 layers)",
+                         "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK, 4),
+                         "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES * (B * T) / 640.0) if args.conv_dtype == "f32" else None,
                          "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
                          "algorithmic_flops_per_frame": conv_flops_per_frame()},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),

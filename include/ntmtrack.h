@@ -58,6 +58,18 @@ int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, const float
                              float* out, int frames, int H, int W, int cin, int cout,
                              int fuse_pool, void* stream);
 
+/* bf16 trunk (BASELINE config 5: "bf16 MFMA conv + fp32 memory"): bf16 NHWC activations and weights, fp32
+ * accumulation (v_mfma_f32_32x32x16_bf16), output rounded once to bf16 (or kept fp32 when out_f32, for the
+ * last layer feeding the memory cell).  Cin a multiple of 64.  Packed weights: bf16 [Cout][9*Cin],
+ * k = (c/64)*576 + (ky*3+kx)*64 + c%64.  conv1_1 (Cin = 3) runs the fp32 kernel on the fp32 frames and
+ * stores bf16 (ntk_vgg_conv3x3_relu_f32_to_bf16, fp32 packed weights from ntk_vgg_pack_weights). */
+int ntk_vgg_pack_weights_bf16(const float* w_hwio, void* w_packed_bf16, int cin, int cout, void* stream);
+int ntk_vgg_conv3x3_relu_bf16(const void* in_bf16, const void* w_packed_bf16, const float* bias, void* out,
+                              int frames, int H, int W, int cin, int cout, int fuse_pool, int out_f32,
+                              void* stream);
+int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, const float* bias, void* out_bf16,
+                                     int frames, int H, int W, int cin, int cout, void* stream);
+
 /* Tuning knob: 0 two LDS buffers / 2 workgroups per CU, 1 = 0 + static wave
  * priority, 2 one LDS buffer / 3 workgroups per CU (default), 3 = 2 at 4
  * workgroups per CU.  All variants compute bit-identical results. */

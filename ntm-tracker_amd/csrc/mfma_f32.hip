@@ -17,6 +17,7 @@
 // 116-118 with two LDS buffers at 2 workgroups/CU (variant 0); static wave
 // priority (1) and 4 workgroups/CU at 128 VGPRs (3, spills) both lose.
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -136,30 +137,7 @@ __device__ __forceinline__ void gemm_pipeline(LA& la, LB& lb, int nk, float* lds
 // pixel patches, patch-major over (frame, py, px); inside a patch
 // q = m & 15 -> window (q>>3, (q>>2)&1), pixel-in-window ((q>>1)&1, q&1).
 // ---------------------------------------------------------------------------
-struct ConvRowInfo {
-    int pix;   // linear pixel index (n*H + y)*W + x, or -1 past the end
-    int yx;    // y << 16 | x
-    int ppix;  // pooled linear pixel index (n*H/2 + y/2)*(W/2) + x/2
-};
-
-__device__ __forceinline__ ConvRowInfo conv_row_info(int m, int npatch, int H, int W) {
-    ConvRowInfo r;
-    const int patch = m >> 4, q = m & 15;
-    if (patch >= npatch) { r.pix = -1; r.yx = 0; r.ppix = -1; return r; }
-    const int PW = W >> 2, PH = H >> 2;
-    const int px = patch % PW;
-    const int t = patch / PW;
-    const int py = t % PH;
-    const int n = t / PH;
-    const int y = py * 4 + (q >> 3) * 2 + ((q >> 1) & 1);
-    const int x = px * 4 + ((q >> 2) & 1) * 2 + (q & 1);
-    r.pix = (n * H + y) * W + x;
-    r.yx = (y << 16) | x;
-    r.ppix = (n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
-    return r;
-}
-
-template <int BN, bool SMALLC, bool POOL, int VAR>
+template <int BN, bool SMALLC, bool POOL, int VAR, bool OUTBF16 = false>
 __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv3x3_relu_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
@@ -260,7 +238,11 @@ __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv
                 for (int r = 0; r < 16; ++r) {
                     const int ml = mbase + (r & 3) + 8 * (r >> 2);
                     const int pix = s_pix[ml];
-                    if (pix >= 0) out[(size_t)pix * Cout + n] = fmaxf(acc[tm][tn][r] + bv, 0.f);
+                    if (pix >= 0) {
+                        const float v = fmaxf(acc[tm][tn][r] + bv, 0.f);
+                        if constexpr (OUTBF16) reinterpret_cast<__bf16*>(out)[(size_t)pix * Cout + n] = (__bf16)v;
+                        else out[(size_t)pix * Cout + n] = v;
+                    }
                 }
             } else {
 #pragma unroll
@@ -269,7 +251,11 @@ __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv
                     const int pp = s_ppix[ml];
                     float v = fmaxf(fmaxf(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1]),
                                     fmaxf(acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
-                    if (pp >= 0) out[(size_t)pp * Cout + n] = fmaxf(v + bv, 0.f);
+                    if (pp >= 0) {
+                        const float o = fmaxf(v + bv, 0.f);
+                        if constexpr (OUTBF16) reinterpret_cast<__bf16*>(out)[(size_t)pp * Cout + n] = (__bf16)o;
+                        else out[(size_t)pp * Cout + n] = o;
+                    }
                 }
             }
         }
@@ -520,6 +506,25 @@ extern "C" int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, 
         else launch_conv<64, false>(in, w_packed, bias, out, npatch, H, W, cin, cout, Kp, fuse_pool, st);
     }
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_f32");
+    return NTK_OK;
+}
+
+// conv1_1 of the bf16 trunk: fp32 frames in, bf16 activations out (same arithmetic, rounded once on store)
+extern "C" int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, const float* bias, void* out_bf16,
+                                                int frames, int H, int W, int cin, int cout, void* stream) {
+    NTK_REQUIRE(in && w_packed && bias && out_bf16, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_f32_to_bf16: null pointer");
+    NTK_REQUIRE(frames > 0 && H > 0 && W > 0 && (H % 4) == 0 && (W % 4) == 0 && H < 32768 && W < 32768 && cin > 0 &&
+                    9 * cin <= BK && cout == 64,
+                NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32_to_bf16: frames=%d H=%d W=%d cin=%d cout=%d (cin <= 3, cout == 64)",
+                frames, H, W, cin, cout);
+    const long npatch_l = (long)frames * (H / 4) * (W / 4);
+    NTK_REQUIRE(npatch_l * 16 < 2147483647L - BM, NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32_to_bf16: too many pixels");
+    const int npatch = (int)npatch_l;
+    const long rtiles = (npatch_l * 16 + BM - 1) / BM;
+    dim3 grid((unsigned)(((rtiles + 7) / 8) * 8));
+    conv3x3_relu_kernel<64, true, false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+        in, w_packed, bias, reinterpret_cast<float*>(out_bf16), npatch, H, W, cin, cout, ntk_vgg_packed_k(cin));
+    NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_f32_to_bf16");
     return NTK_OK;
 }
 

@@ -57,15 +57,42 @@ def pack_weights(w_hwio):
     return wp
 
 
+def conv3x3_relu_bf16(x, w_packed, bias, cin, cout, fuse_pool=False, out_f32=False, out=None):
+    """bf16 NHWC activations [F,H,W,Cin] -> relu(conv3x3_same(x)+b) in bf16 (or fp32 when out_f32)."""
+    F, H, W, C = x.shape
+    if C != cin or x.dtype != torch.bfloat16:
+        raise _lib.NtkError("conv3x3_relu_bf16: expected bf16 input with %d channels" % cin)
+    oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
+    if out is None:
+        out = torch.empty((F, oh, ow, cout), device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_bf16(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out), F, H, W,
+                                                    cin, cout, 1 if fuse_pool else 0, 1 if out_f32 else 0, _lib.stream()),
+               "ntk_vgg_conv3x3_relu_bf16")
+    return out
+
+
+def pack_weights_bf16(w_hwio):
+    kh, kw, cin, cout = w_hwio.shape
+    wp = torch.empty((cout, 9 * cin), device=w_hwio.device, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().ntk_vgg_pack_weights_bf16(_lib.ptr(w_hwio.contiguous()), _lib.ptr(wp), cin, cout, _lib.stream()),
+               "ntk_vgg_pack_weights_bf16")
+    return wp
+
+
 class VGG16Conv43(object):
     """Frozen VGG-16 trunk up to conv4_3/Relu.
 
     weights: {layer_name: (w_hwio [3,3,Cin,Cout], b [Cout])} as numpy arrays or tensors.
+    dtype "f32" (BASELINE configs 2-4: exact fp32 MFMA) or "bf16" (config 5: bf16 operands, fp32 accumulate;
+    conv1_1 reads the fp32 frames, conv4_3 writes fp32 for the memory cell).
     """
 
-    def __init__(self, weights, device="cuda", chunk_frames=1024):
+    def __init__(self, weights, device="cuda", chunk_frames=1024, dtype="f32"):
         self.device = torch.device(device)
         self.chunk_frames = int(chunk_frames)
+        if dtype not in ("f32", "bf16"):
+            raise _lib.NtkError("VGG16Conv43: dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
         self.packed = {}
         for name, cin, cout, _pool in VGG_LAYERS:
             w, b = weights[name]
@@ -73,9 +100,29 @@ class VGG16Conv43(object):
             b = torch.as_tensor(b, dtype=torch.float32).to(self.device).contiguous()
             if tuple(w.shape) != (3, 3, cin, cout):
                 raise _lib.NtkError("%s: weight shape %s != (3,3,%d,%d)" % (name, tuple(w.shape), cin, cout))
-            self.packed[name] = (pack_weights(w), b)
+            if dtype == "bf16" and cin % 64 == 0:
+                self.packed[name] = (pack_weights_bf16(w), b)
+            else:
+                self.packed[name] = (pack_weights(w), b)
+
+    def _forward_chunk_bf16(self, frames, out=None):
+        F, H, W, _ = frames.shape
+        L = _lib.lib()
+        wp, b = self.packed["conv1_1"]
+        x = torch.empty((F, H, W, 64), device=frames.device, dtype=torch.bfloat16)
+        _lib.check(L.ntk_vgg_conv3x3_relu_f32_to_bf16(_lib.ptr(frames), _lib.ptr(wp), _lib.ptr(b), _lib.ptr(x), F, H, W, 3, 64,
+                                                      _lib.stream()), "ntk_vgg_conv3x3_relu_f32_to_bf16")
+        for name, cin, cout, pool in VGG_LAYERS[1:]:
+            wp, b = self.packed[name]
+            last = (name == "conv4_3")
+            x = conv3x3_relu_bf16(x, wp, b, cin, cout, fuse_pool=pool, out_f32=last, out=out if last else None)
+        return x
 
     def forward_chunk(self, frames, upto="conv4_3", out=None):
+        if self.dtype == "bf16":
+            if upto != "conv4_3":
+                raise _lib.NtkError("bf16 trunk runs to conv4_3 only")
+            return self._forward_chunk_bf16(frames.contiguous(), out=out)
         x = frames
         for name, cin, cout, pool in VGG_LAYERS:
             wp, b = self.packed[name]

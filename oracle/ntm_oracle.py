@@ -409,3 +409,32 @@ def rmsprop_step(param, grad, ms, mom, lr=1e-4, decay=0.95, momentum=0.9, eps=1e
     ms = dt.type(decay) * ms + dt.type(1 - decay) * grad * grad
     mom = dt.type(momentum) * mom + dt.type(lr) * grad / np.sqrt(ms + dt.type(eps))
     return (param - mom).astype(dt), ms.astype(dt), mom.astype(dt)
+
+
+# --------------------------------------------------------------------------
+# bf16-operand variant of the trunk (BASELINE config 5: bf16 MFMA conv, fp32 accumulate)
+# --------------------------------------------------------------------------
+def bf16_round(x):
+    """Round fp32 -> bf16 (round to nearest even) and return as fp32."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+def vgg16_conv43_bf16(frames, weights):
+    """conv1_1 in fp32 on the fp32 frames (output rounded to bf16); every later layer multiplies bf16
+    activations by bf16-rounded weights, accumulates wide, adds the fp32 bias, ReLU (+pool), and rounds the
+    stored activation to bf16 -- except conv4_3, which stays fp32 for the memory cell."""
+    x = frames.astype(np.float32)
+    for name, _cin, _cout, pool in VGG_LAYERS:
+        w, b = weights[name]
+        if name == "conv1_1":
+            y = conv3x3_same_relu(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+        else:
+            y = conv3x3_same_relu(x.astype(np.float64), bf16_round(w).astype(np.float64), b.astype(np.float64))
+        if name == "conv4_3":
+            return y.astype(np.float32)
+        if pool:
+            y = maxpool2x2(y)
+        x = bf16_round(y.astype(np.float32))
+    return x

@@ -64,3 +64,52 @@ def test_vgg_trunk_matches_oracle_small(cuda):
     got = out.cpu().numpy()
     assert got.shape == (2, 4, 4, 512)
     assert _rel(got, ref) < 1e-4   # north_star tolerance (1e-4 fp32) through 10 layers
+
+
+# ---- bf16 trunk (BASELINE config 5)
+@pytest.mark.parametrize("F,H,W,cin,cout,pool,out_f32", [
+    (2, 8, 12, 64, 64, True, False),
+    (1, 16, 16, 64, 128, False, False),
+    (1, 28, 28, 256, 512, False, True),
+    (3, 4, 4, 128, 256, True, False),
+])
+def test_conv3x3_relu_bf16_matches_bf16_oracle(cuda, F, H, W, cin, cout, pool, out_f32):
+    """Operands rounded to bf16 in the oracle exactly as the kernel sees them; fp32 accumulation order is the
+    only difference, plus one bf16 rounding of the stored result (half an ulp = 2^-9 relative)."""
+    from ntmtrack import vgg
+    rng = np.random.default_rng(9)
+    x = O.bf16_round(rng.standard_normal((F, H, W, cin)).astype(np.float32))
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    ref = O.conv3x3_same_relu(x.astype(np.float64), O.bf16_round(w).astype(np.float64), b.astype(np.float64))
+    if pool:
+        ref = O.maxpool2x2(ref)
+    wp = vgg.pack_weights_bf16(torch.from_numpy(w).to(cuda))
+    out = vgg.conv3x3_relu_bf16(torch.from_numpy(x).to(cuda).to(torch.bfloat16), wp, torch.from_numpy(b).to(cuda), cin, cout,
+                                fuse_pool=pool, out_f32=out_f32)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert got.shape == ref.shape
+    scale = np.max(np.abs(ref))
+    if out_f32:
+        assert np.max(np.abs(got - ref)) / scale < 1e-5
+    else:
+        assert np.max(np.abs(got - ref) / (np.abs(ref) + 1e-3 * scale)) < 2.0 ** -8      # one bf16 rounding of the output
+
+
+def test_vgg_trunk_bf16_matches_bf16_oracle(cuda):
+    from ntmtrack import vgg
+    rng = np.random.default_rng(43)
+    ws = O.init_vgg_weights(rng)
+    frames = (rng.uniform(0, 255, size=(2, 32, 32, 3)).astype(np.float32) - O.VGG_MEAN)
+    ref = O.vgg16_conv43_bf16(frames, ws)
+    ref32 = O.vgg16_conv43(frames.astype(np.float64), {k: (w.astype(np.float64), b.astype(np.float64)) for k, (w, b) in ws.items()})
+    net = vgg.VGG16Conv43(ws, device=cuda, dtype="bf16")
+    got = net(torch.from_numpy(frames).to(cuda)).cpu().numpy()
+    torch.cuda.synchronize()
+    scale = np.max(np.abs(ref))
+    # vs the bf16-emulating oracle: activation roundings can land on the other side of a tie after a different
+    # accumulation order -> a few bf16 ulps through 9 bf16 layers
+    assert np.max(np.abs(got - ref)) / scale < 2e-2
+    # and the bf16 trunk stays within ~1 % of the fp32 trunk (the stated tolerance of config 5's conv)
+    assert np.max(np.abs(got - ref32)) / np.max(np.abs(ref32)) < 3e-2
