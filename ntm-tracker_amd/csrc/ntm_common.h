@@ -60,5 +60,23 @@ static inline __host__ __device__ int ntm_imax(int a, int b) { return a > b ? a 
 static inline __host__ __device__ int ntm_imin(int a, int b) { return a < b ? a : b; }
 static inline __host__ __device__ int ntm_align4(int x) { return (x + 3) & ~3; }
 
+// Elementwise math of the recurrence.  NTM_FAST_MATH (default) maps exp/log/pow/division onto the hardware
+// transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1-2 ulp): ~10x fewer instructions on the serial
+// critical path of a step; tests/test_ntm_gpu.py::test_full_length_sequence_drift bounds the accumulated
+// effect over 1300 steps against the float64 oracle (north_star tolerance 1e-4).
+#ifndef NTM_FAST_MATH
+#define NTM_FAST_MATH 1
+#endif
+#if NTM_FAST_MATH
+__device__ __forceinline__ float ntm_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float ntm_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+__device__ __forceinline__ float ntm_tanh(float x) { return 1.0f - __fdividef(2.0f, 1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float ntm_softplus(float x) { return fmaxf(x, 0.f) + __logf(1.0f + __expf(-fabsf(x))); }
+__device__ __forceinline__ float ntm_pow(float x, float y) { return x > 0.f ? __expf(y * __logf(x)) : 0.f; }
+#else
+__device__ __forceinline__ float ntm_exp(float x) { return expf(x); }
 __device__ __forceinline__ float ntm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float ntm_tanh(float x) { return tanhf(x); }
 __device__ __forceinline__ float ntm_softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float ntm_pow(float x, float y) { return powf(x, y); }
+#endif

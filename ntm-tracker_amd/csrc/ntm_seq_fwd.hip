@@ -67,7 +67,7 @@ static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
     L.Cn = o; o += ntm_align4(d.Md);
     L.CnPart = o; o += ntm_align4(nslC * d.Md);
     L.Sw = o; o += ntm_align4(d.H * d.SS);
-    L.Red = o; o += ntm_align4(2 * d.H * (d.N / 64));
+    L.Red = o; o += ntm_align4(d.H * d.N);
     L.total = o;
 }
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
     const int b = blockIdx.x, tid = threadIdx.x, T = FIX ? 640 : blockDim.x;
     const int N = FIX ? 128 : a.d.N, Md = FIX ? 20 : a.d.Md, MP = Md | 1, R = FIX ? 4 : a.d.R, Wh = FIX ? 1 : a.d.Wh;
     const int H = R + Wh, hid = FIX ? 200 : a.d.hid, SS = FIX ? 3 : a.d.SS;
-    const int S = a.d.S, RM = R * Md, K = RM + hid, NW = N >> 6;
+    const int S = a.d.S, RM = R * Md, K = RM + hid;
     struct {
         int O, oK, oB, oG, oS, oY, oE, oA, P, PP, ldz, ldh, write_first;
     } d;
@@ -100,10 +100,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
     float* sU = smem + L.U;
     float* sKs = smem + L.Ks;
     float* sCn = smem + L.Cn;
-    float* sCnPart = smem + L.CnPart;
-    float* sSw = smem + L.Sw;
-    float* sRedMax = smem + L.Red;
-    float* sRedSum = sRedMax + H * NW;
+    float* sPw = smem + L.Red;             // [H][N] sharpened weights before normalisation
 
     // work decomposition (uniform per kernel)
     const int nsl = max(1, T / hid);                 // K-slices of the gate product
@@ -113,8 +110,6 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
     const int kperB = (hid + nslB - 1) / nslB;
     const int nslR = min(max(1, T / RM), N);          // N-slices of the read product
     const int nperR = (N + nslR - 1) / nslR;
-    const int nslC = max(1, (T - hid) / Md);          // N-slices of the column sum of squares
-    const int hpp = T / N;                            // heads handled per pass of P6/P7
 
     // ---- load the initial state
     for (int i = tid; i < N * Md; i += T) sM[(i / Md) * MP + (i % Md)] = a.M0[(size_t)b * N * Md + i];
@@ -182,16 +177,17 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             sPart4[ks * hid + j] = acc;
         }
         __syncthreads();
-        // ------------------------------------------------------------ P2
+        // ------------------------------------------------------------ P2: LSTM cell  ||  column norms of M (Q1)
+        const int wave = tid >> 6, nwaves = T >> 6;
         if (tid < hid) {
             f32x4 g = xg;
             for (int ks = 0; ks < nsl; ++ks) g += sPart4[ks * hid + tid];
             const float gi = ntm_sigmoid(g[0]);
-            const float gj = tanhf(g[1]);
+            const float gj = ntm_tanh(g[1]);
             const float gf = ntm_sigmoid(g[2]);      // forget_bias = 0.0 (ntm_cell.py:47)
             const float go = ntm_sigmoid(g[3]);
             const float c2 = sC[tid] * gf + gi * gj;
-            const float h2 = tanhf(c2) * go;
+            const float h2 = ntm_tanh(c2) * go;
             sC[tid] = c2;
             sZ[RM + tid] = h2;
             if (a.st_gates) {
@@ -200,18 +196,22 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
                 a.st_c[bt * hid + tid] = c2;
             }
             if (a.st_h) a.st_h[bt * d.ldh + tid] = h2;
-        } else {
-            const int idx = tid - hid;
-            const int m = idx % Md, sl = idx / Md;
-            if (sl < nslC) {
-                float s = 0.f;
-                for (int n = sl; n < N; n += nslC) { const float v = sM[n * MP + m]; s += v * v; }
-                sCnPart[sl * Md + m] = s;
+        } else if (a.st_h && tid < d.ldh) {
+            a.st_h[bt * d.ldh + tid] = (tid == hid) ? 1.f : 0.f;
+        }
+        {   // waves not running the LSTM normalise the feature columns over the slot axis (tf.nn.l2_normalize, ops.py:150)
+            const int w0 = (hid + 63) >> 6;
+            if (wave >= w0) {
+                for (int m = wave - w0; m < Md; m += nwaves - w0) {
+                    float s = 0.f;
+                    for (int n = lane; n < N; n += 64) { const float v = sM[n * MP + m]; s += v * v; }
+                    s = wave_sum(s);
+                    if (lane == 0) sCn[m] = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+                }
             }
-            if (a.st_h && idx < d.ldh - hid) a.st_h[bt * d.ldh + hid + idx] = (idx == 0) ? 1.f : 0.f;
         }
         __syncthreads();
-        // ------------------------------------------------------------ P3
+        // ------------------------------------------------------------ P3: unpack / output partials
         if (tid < nslB * ncg) {
             const int cg = tid % ncg, ks = tid / ncg;
             const int k0 = ks * kperB, k1 = min(hid, k0 + kperB);
@@ -226,42 +226,89 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             sPart4[ks * ncg + cg] = acc;
         }
         __syncthreads();
-        // ------------------------------------------------------------ P4
+        // ------------------------------------------------------------ P4: control activations
         if (tid < PP) {
             float v = a.Wa[(size_t)hid * PP + tid];
             for (int ks = 0; ks < nslB; ++ks) v += sPart[ks * PP + tid];
             float r = v;
-            if (tid < d.oB) r = tanhf(v);                          // k      :133
+            if (tid < d.oB) r = ntm_tanh(v);                       // k      :133
             else if (tid < d.oG) r = ntm_softplus(v);              // beta   :140
             else if (tid < d.oS) r = ntm_sigmoid(v);               // g      :151
-            else if (tid < d.oY) r = v;                            // shift logits (softmax in P5)
+            else if (tid < d.oY) r = v;                            // shift logits (softmax per head below)
             else if (tid < d.oE) r = ntm_softplus(v) + 1.0f;       // gamma  :169-170
             else if (tid < d.oA) r = ntm_sigmoid(v);               // erase  :193
-            else if (tid < d.P) r = tanhf(v);                      // add    :195
+            else if (tid < d.P) r = ntm_tanh(v);                   // add    :195
             sU[tid] = r;
             if (a.st_u) a.st_u[bt * PP + tid] = r;
             if (tid >= d.P && tid < d.P + d.O) a.logits[bt * d.O + (tid - d.P)] = v;
-        } else if (tid < PP + Md) {
-            const int m = tid - PP;
-            float s = 0.f;
-            for (int sl = 0; sl < nslC; ++sl) s += sCnPart[sl * Md + m];
-            sCn[m] = 1.0f / sqrtf(fmaxf(s, 1e-12f));             // tf.nn.l2_normalize over the slot axis (Q1)
         }
         __syncthreads();
-        // ------------------------------------------------------------ P5
-        if (tid < H * Md) {
-            const int h = tid / Md, m = tid - h * Md;
-            float ss = 0.f;
-            for (int mm = 0; mm < Md; ++mm) { const float kv = sU[d.oK + h * Md + mm]; ss += kv * kv; }
-            sKs[tid] = sU[d.oK + tid] * (1.0f / sqrtf(fmaxf(ss, 1e-12f))) * sCn[m];
-        } else if (tid < H * Md + H) {
-            const int h = tid - H * Md;
-            float mx = -INFINITY;
-            for (int j = 0; j < SS; ++j) mx = fmaxf(mx, sU[d.oS + h * SS + j]);
+        // ------------------------------------------------------------ P5-P7: one WAVE per head, no workgroup barrier inside:
+        // key scaling, similarity (Q1), beta, softmax over N, gate, circular shift (Q2), sharpen (Q4)
+        if (wave < H) {
+            const int h = wave;
+            float kss = 0.f;
+            for (int m = 0; m < Md; ++m) { const float kv = sU[d.oK + h * Md + m]; kss += kv * kv; }
+            const float kinv = 1.0f / sqrtf(fmaxf(kss, 1e-12f));
+            if (lane < Md) sKs[h * Md + lane] = sU[d.oK + h * Md + lane] * kinv * sCn[lane];
+            for (int m = lane + 64; m < Md; m += 64) sKs[h * Md + m] = sU[d.oK + h * Md + m] * kinv * sCn[m];
+            const float beta = sU[d.oB + h], g = sU[d.oG + h], gamma = sU[d.oY + h];
+            float swv[5];                                          // softmax of the shift logits (ntm_cell.py:161)
+            {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) if (j < SS) mx = fmaxf(mx, sU[d.oS + h * SS + j]);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { swv[j] = (j < SS) ? ntm_exp(sU[d.oS + h * SS + j] - mx) : 0.f; sum += swv[j]; }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) swv[j] = swv[j] / sum;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float mxv = -INFINITY;
+            for (int n = lane; n < N; n += 64) {
+                float sim = 0.f;
+                for (int m = 0; m < Md; ++m) sim += sKs[h * Md + m] * sM[n * MP + m];
+                const float v = sim * beta;
+                sWg[h * N + n] = v;
+                mxv = fmaxf(mxv, v);
+            }
+            mxv = wave_max(mxv);
             float sum = 0.f;
-            for (int j = 0; j < SS; ++j) sum += expf(sU[d.oS + h * SS + j] - mx);
-            for (int j = 0; j < SS; ++j) sSw[h * SS + j] = expf(sU[d.oS + h * SS + j] - mx) / sum;
-        } else if (tid == H * Md + H && a.outputs) {
+            for (int n = lane; n < N; n += 64) { const float e = ntm_exp(sWg[h * N + n] - mxv); sWg[h * N + n] = e; sum += e; }
+            sum = wave_sum(sum);
+            for (int n = lane; n < N; n += 64) {
+                const float wc = sWg[h * N + n] / sum;
+                if (a.st_wc) a.st_wc[(bt * H + h) * N + n] = wc;
+                sWg[h * N + n] = wc * g + sW[h * N + n] * (1.0f - g);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int start = -((SS + 1) >> 1);                    // Py2 floor of -SS/2 (Q2): 3 -> -2
+            float psum = 0.f;
+            for (int n = lane; n < N; n += 64) {
+                float wv = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if (j < SS) {
+                        int src = n + start + j;
+                        src = (src % N + N) % N;
+                        wv += swv[j] * sWg[h * N + src];
+                    }
+                }
+                if (a.st_wv) a.st_wv[(bt * H + h) * N + n] = wv;
+                const float pw = ntm_pow(wv, gamma);
+                sPw[h * N + n] = pw;
+                psum += pw;
+            }
+            psum = wave_sum(psum);
+            for (int n = lane; n < N; n += 64) {
+                const float w = sPw[h * N + n] / (psum + 1e-3f);
+                sW[h * N + n] = w;
+                if (a.st_w) a.st_w[(bt * H + h) * N + n] = w;
+            }
+        } else if (wave == H && lane == 0 && a.outputs) {
             float mx = -INFINITY;
             for (int j = 0; j < d.O; ++j) mx = fmaxf(mx, sU[d.P + j]);
             float sum = 0.f;
@@ -269,69 +316,6 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             for (int j = 0; j < d.O; ++j) a.outputs[bt * d.O + j] = expf(sU[d.P + j] - mx) / sum;
         }
         __syncthreads();
-        // ------------------------------------------------------------ P6: content addressing + gate
-        for (int h0 = 0; h0 < H; h0 += hpp) {
-            const int hl = tid / N, n = tid - hl * N, h = h0 + hl;
-            const bool act = (hl < hpp) && (h < H);
-            const int wi = n >> 6;
-            float v = -INFINITY;
-            if (act) {
-                float sim = 0.f;
-                for (int m = 0; m < Md; ++m) sim += sKs[h * Md + m] * sM[n * MP + m];
-                v = sim * sU[d.oB + h];
-            }
-            const float wmx = wave_max(v);
-            if (act && lane == 0) sRedMax[h * NW + wi] = wmx;
-            __syncthreads();
-            float e = 0.f;
-            if (act) {
-                float mx = sRedMax[h * NW];
-                for (int q = 1; q < NW; ++q) mx = fmaxf(mx, sRedMax[h * NW + q]);
-                e = expf(v - mx);
-            }
-            const float wsm = wave_sum(e);
-            if (act && lane == 0) sRedSum[h * NW + wi] = wsm;
-            __syncthreads();
-            if (act) {
-                float tot = 0.f;
-                for (int q = 0; q < NW; ++q) tot += sRedSum[h * NW + q];
-                const float wc = e / tot;
-                const float g = sU[d.oG + h];
-                const float wg = wc * g + sW[h * N + n] * (1.0f - g);
-                sWg[h * N + n] = wg;
-                if (a.st_wc) a.st_wc[(bt * H + h) * N + n] = wc;
-            }
-        }
-        __syncthreads();
-        // ------------------------------------------------------------ P7: shift + sharpen
-        for (int h0 = 0; h0 < H; h0 += hpp) {
-            const int hl = tid / N, n = tid - hl * N, h = h0 + hl;
-            const bool act = (hl < hpp) && (h < H);
-            const int wi = n >> 6;
-            float pw = 0.f;
-            if (act) {
-                float wv = 0.f;
-                const int start = -((SS + 1) >> 1);              // Py2 floor of -SS/2 (Q2): 3 -> -2
-                for (int j = 0; j < SS; ++j) {
-                    int src = n + start + j;
-                    src = (src % N + N) % N;
-                    wv += sSw[h * SS + j] * sWg[h * N + src];
-                }
-                if (a.st_wv) a.st_wv[(bt * H + h) * N + n] = wv;
-                pw = powf(wv, sU[d.oY + h]);
-            }
-            const float wsm = wave_sum(pw);
-            if (act && lane == 0) sRedSum[h * NW + wi] = wsm;
-            __syncthreads();
-            if (act) {
-                float tot = 0.f;
-                for (int q = 0; q < NW; ++q) tot += sRedSum[h * NW + q];
-                const float w = pw / (tot + 1e-3f);
-                sW[h * N + n] = w;
-                if (a.st_w) a.st_w[(bt * H + h) * N + n] = w;
-            }
-            __syncthreads();
-        }
         // ------------------------------------------------------------ P8: write + read
         auto update_M = [&]() {
             for (int idx = tid; idx < N * Md; idx += T) {
@@ -383,6 +367,8 @@ static int ntm_pick_threads(const NtmDims& d) {
     want = ntm_imax(want, d.hid + ntm_imax(d.Md, 4));
     want = ntm_imax(want, d.PP + d.Md);
     want = ntm_imax(want, d.H * d.Md + d.H + 1);
+    want = ntm_imax(want, ((d.hid + 63) / 64 + 1) * 64);
+    want = ntm_imax(want, (d.H + 1) * 64);
     want = ((want + 63) / 64) * 64;
     if (want > 1024) want = 1024;
     return want;
