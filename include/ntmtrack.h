@@ -207,6 +207,10 @@ int ntk_gather_serialize(const float* fmap, const float* gts0, float* X, int B, 
 int ntk_offset_loss(const float* logits, const float* offsets, float* pred, float* loss,
                     float* dlogits, int B, int T, int NF, int O, void* stream);
 
+/* copy-task head (main.py:1603-1610, BASELINE configs[0]): loss = tf.losses.log_loss(labels,
+ * sigmoid(logits)) (mean over all n elements, epsilon 1e-7) and d loss / d logits (nullable). */
+int ntk_log_loss(const float* logits, const float* labels, float* loss, float* dlogits, int n, void* stream);
+
 /* ------------------------------------------------------------------------
  * optimiser (direct_offset_output.py:620-626): tf.clip_by_global_norm +
  * tf.train.RMSPropOptimizer on one flat buffer

@@ -43,6 +43,7 @@ def _sig(lib):
         "ntk_dnc_seq_bwd": (c_int, [c_int] * 8 + [ctypes.c_float] + [P, c_int, P, c_int, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P]),
         "ntk_gather_serialize": (c_int, [P, P, P] + [c_int] * 9 + [P]),
         "ntk_offset_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+        "ntk_log_loss": (c_int, [P, P, P, P, c_int, P]),
         "ntk_ntm_init_state": (c_int, [P, P, c_int, c_int, c_int, P]),
         "ntk_ntm_init_state_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_global_norm_workspace_bytes": (c_size_t, [c_size_t]),

@@ -74,6 +74,29 @@ __global__ __launch_bounds__(1024) void offset_loss_kernel(const float* __restri
     }
 }
 
+// copy task head (main.py:1603-1610): p = sigmoid(logit); loss = mean(-(y log(p+eps) + (1-y) log(1-p+eps))), eps = 1e-7
+// (tf.losses.log_loss defaults); dlogits = d loss / d logit.  Single workgroup, fixed-order reduction.
+__global__ __launch_bounds__(1024) void log_loss_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                         float* __restrict__ loss, float* __restrict__ dlogits, int n) {
+    __shared__ float red[16];
+    const float eps = 1e-7f, inv = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float p = 1.0f / (1.0f + expf(-logits[i]));
+        const float y = labels[i];
+        acc += -(y * logf(p + eps) + (1.0f - y) * logf(1.0f - p + eps));
+        if (dlogits) dlogits[i] = inv * (-(y / (p + eps)) + (1.0f - y) / (1.0f - p + eps)) * p * (1.0f - p);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        *loss = s * inv;
+    }
+}
+
 // act: 0 = tanh, 1 = sigmoid.  out[b][i] = act(v[i])
 __global__ void init_state_kernel(const float* __restrict__ v, float* __restrict__ out, int n, int B, int act) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,6 +198,14 @@ extern "C" int ntk_offset_loss(const float* logits, const float* offsets, float*
     NTK_REQUIRE(B > 0 && T >= 2 && NF > 0 && O > 0, NTK_ERR_BAD_SHAPE, "ntk_offset_loss: B=%d T=%d NF=%d O=%d (T >= 2)", B, T, NF, O);
     offset_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, offsets, pred, loss, dlogits, B, T, NF, O);
     NTK_CHECK_LAUNCH("ntk_offset_loss");
+    return NTK_OK;
+}
+
+extern "C" int ntk_log_loss(const float* logits, const float* labels, float* loss, float* dlogits, int n, void* stream) {
+    NTK_REQUIRE(logits && labels && loss, NTK_ERR_BAD_PTR, "ntk_log_loss: null pointer");
+    NTK_REQUIRE(n > 0, NTK_ERR_BAD_SHAPE, "ntk_log_loss: n=%d", n);
+    log_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, labels, loss, dlogits, n);
+    NTK_CHECK_LAUNCH("ntk_log_loss");
     return NTK_OK;
 }
 
