@@ -71,7 +71,8 @@ int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, con
                                      int frames, int H, int W, int cin, int cout, void* stream);
 
 /* Tuning knob: 0 two LDS buffers / 2 workgroups per CU, 1 = 0 + static wave
- * priority, 2 one LDS buffer / 3 workgroups per CU (default), 3 = 2 at 4
+ * priority, 2 one LDS buffer / 3 workgroups per CU, 3 = 2 at 4 workgroups per
+ * CU (spills), 4 (default) LDS-DMA staging, swizzled un-padded LDS image, 4
  * workgroups per CU.  All variants compute bit-identical results. */
 int ntk_vgg_set_conv_variant(int variant);
 

@@ -16,6 +16,8 @@
 // K-tile, 38 KB) so that 3 workgroups fit a CU: 126-128 TFLOP/s per layer vs
 // 116-118 with two LDS buffers at 2 workgroups/CU (variant 0); static wave
 // priority (1) and 4 workgroups/CU at 128 VGPRs (3, spills) both lose.
+// Variant 4 (shipped): LDS-DMA staging (global_load_lds_dwordx4) frees the 32
+// staging VGPRs -> 128 VGPRs, 32 KB LDS, FOUR workgroups per CU: 132-133 TFLOP/s.
 #include "common.h"
 #include "conv_common.h"
 
@@ -262,6 +264,143 @@ __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv
     }
 }
 
+// ---------------------------------------------------------------------------
+// Variant 4: operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no ds_write),
+// one un-padded XOR-swizzled LDS buffer, 4 workgroups per CU.  LDS image: row r at byte r*128, its 16-byte
+// chunk c stored in slot c ^ ((r >> 1) & 7): every ds_read_b128 lane group of the fragment reads then touches 16
+// distinct 4-bank slots (rows of one parity x 8 slots).  One DMA wave-instruction fills 8 rows (1 KB,
+// lane-linear), so the swizzle is applied to the per-lane SOURCE address.  Zero padding (image border, rows past
+// the end) is fetched from a zero page.
+// ---------------------------------------------------------------------------
+__device__ __attribute__((aligned(128))) float g_zero_page[32];
+
+template <int BN>
+__device__ __forceinline__ void mma_ktile_swz(const float* __restrict__ As, const float* __restrict__ Bs,
+                                              f32x16 (&acc)[2][BN / 64], int wm, int wn, int lane) {
+    constexpr int TN = BN / 64;
+    const int i = lane & 31, kh = lane >> 5, f = (i >> 1) & 7;
+    const float* ap = As + (wm * 64 + i) * BK;
+    const float* bp = Bs + (wn * (BN / 2) + i) * BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int slot = ((2 * q + kh) ^ f) * 4;
+        f32x4 a[2], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(ap + tm * 32 * BK + slot);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(bp + tn * 32 * BK + slot);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void lds_dma16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN, bool POOL>
+__global__ __launch_bounds__(256, 4) void conv3x3_relu_dma_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
+    constexpr int TN = BN / 64, NBI = BN / 32;      // B DMA instructions per wave
+    __shared__ __attribute__((aligned(1024))) float lds[(BM + BN) * BK];
+    __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
+
+    const int tid = threadIdx.x;
+    const int ctiles = Cout / BN;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int rt = (li / ctiles) * 8 + xcd;
+    const int m0 = rt * BM;
+    const int n0 = (li % ctiles) * BN;
+    if (m0 >= npatch * 16) return;
+    if (tid < BM) {
+        ConvRowInfo ri = conv_row_info(m0 + tid, npatch, H, W);
+        s_pix[tid] = ri.pix; s_yx[tid] = ri.yx; s_ppix[tid] = ri.ppix;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // DMA roles: instruction jj of this wave fills tile rows (wave*4 + jj)*8 .. +7; lane -> (row = lane>>3, slot = lane&7)
+    const int lr = lane >> 3, slot = lane & 7;
+    int rpix[4], ry[4], rx[4], achunk[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int r = (wave * 4 + jj) * 8 + lr;
+        rpix[jj] = s_pix[r];
+        const int yx = s_yx[r];
+        ry[jj] = yx >> 16; rx[jj] = yx & 0xffff;
+        achunk[jj] = (slot ^ ((r >> 1) & 7)) * 4;
+    }
+    const float* bsrc[NBI];
+#pragma unroll
+    for (int jj = 0; jj < NBI; ++jj) {
+        const int r = (wave * NBI + jj) * 8 + lr;
+        bsrc[jj] = wp + (size_t)(n0 + r) * Kp + (slot ^ ((r >> 1) & 7)) * 4;
+    }
+    float* As = lds;
+    float* Bs = lds + BM * BK;
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nk = Kp / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int chunk = kt / 9, tap = kt - chunk * 9;
+        const int c0 = chunk * BK;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        if (kt > 0) __syncthreads();                       // every wave has finished reading the previous tile
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int yy = ry[jj] + dy, xx = rx[jj] + dx;
+            const bool ok = rpix[jj] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const float* src = ok ? in + (size_t)(rpix[jj] + dy * W + dx) * Cin + c0 + achunk[jj] : g_zero_page + (lane & 7) * 4;
+            lds_dma16(src, As + (wave * 4 + jj) * 8 * BK);
+        }
+#pragma unroll
+        for (int jj = 0; jj < NBI; ++jj) lds_dma16(bsrc[jj] + kt * BK, Bs + (wave * NBI + jj) * 8 * BK);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // all four waves' DMA has landed
+        mma_ktile_swz<BN>(As, Bs, acc, wm, wn, lane);
+    }
+
+    const int kh = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * (BN / 2) + tn * 32 + col;
+        const float bv = bias[n];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int mbase = wm * 64 + tm * 32 + 4 * kh;
+            if constexpr (!POOL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = s_pix[mbase + (r & 3) + 8 * (r >> 2)];
+                    if (pix >= 0) out[(size_t)pix * Cout + n] = fmaxf(acc[tm][tn][r] + bv, 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int pp = s_ppix[mbase + 8 * g];
+                    const float v = fmaxf(fmaxf(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1]),
+                                          fmaxf(acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
+                    if (pp >= 0) out[(size_t)pp * Cout + n] = fmaxf(v + bv, 0.f);
+                }
+            }
+        }
+    }
+}
+
 // HWIO [3,3,Cin,Cout] -> [Cout][Kp].  Cin % 32 == 0: k = (c/32)*288 + tap*32 + c%32 (chunk outer, tap inner);
 // tiny Cin (conv1_1): k = tap*Cin + c, zero padded to Kp.
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int Kp) {
@@ -458,21 +597,31 @@ static void launch_conv_v(const float* in, const float* wp, const float* bias, f
         conv3x3_relu_kernel<BN, SMALLC, false, VAR><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
 }
 
-static int g_conv_variant = 2;   // tuning knob (ntk_vgg_set_conv_variant); every variant computes identical results
+static int g_conv_variant = 4;   // tuning knob (ntk_vgg_set_conv_variant); every variant computes identical results
 
 template <int BN, bool SMALLC>
 static void launch_conv(const float* in, const float* wp, const float* bias, float* out, int npatch,
                         int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
+    if constexpr (!SMALLC) {
+        if (g_conv_variant == 4) {
+            const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
+            dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
+            if (pool) conv3x3_relu_dma_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+            else conv3x3_relu_dma_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+            return;
+        }
+    }
     switch (g_conv_variant) {
         case 1: launch_conv_v<BN, SMALLC, 1>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
         case 2: launch_conv_v<BN, SMALLC, 2>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
         case 3: launch_conv_v<BN, SMALLC, 3>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
-        default: launch_conv_v<BN, SMALLC, 0>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
+        case 0: launch_conv_v<BN, SMALLC, 0>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
+        default: launch_conv_v<BN, SMALLC, 2>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;   // 4 with Cin = 3
     }
 }
 
 extern "C" int ntk_vgg_set_conv_variant(int v) {
-    NTK_REQUIRE(v >= 0 && v <= 3, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d", v);
+    NTK_REQUIRE(v >= 0 && v <= 4, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d", v);
     g_conv_variant = v;
     return NTK_OK;
 }
