@@ -63,6 +63,7 @@ int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, const float
  * last layer feeding the memory cell).  Cin a multiple of 64.  Packed weights: bf16 [Cout][9*Cin],
  * k = (c/64)*576 + (ky*3+kx)*64 + c%64.  conv1_1 (Cin = 3) runs the fp32 kernel on the fp32 frames and
  * stores bf16 (ntk_vgg_conv3x3_relu_f32_to_bf16, fp32 packed weights from ntk_vgg_pack_weights). */
+int ntk_vgg_set_bf16_conv_variant(int variant);   /* 1 (default) LDS-DMA staging, 0 VGPR staging; same results */
 int ntk_vgg_pack_weights_bf16(const float* w_hwio, void* w_packed_bf16, int cin, int cout, void* stream);
 int ntk_vgg_conv3x3_relu_bf16(const void* in_bf16, const void* w_packed_bf16, const float* bias, void* out,
                               int frames, int H, int W, int cin, int cout, int fuse_pool, int out_f32,
@@ -73,7 +74,9 @@ int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, con
 /* Tuning knob: 0 two LDS buffers / 2 workgroups per CU, 1 = 0 + static wave
  * priority, 2 one LDS buffer / 3 workgroups per CU, 3 = 2 at 4 workgroups per
  * CU (spills), 4 (default) LDS-DMA staging, swizzled un-padded LDS image, 4
- * workgroups per CU.  All variants compute bit-identical results. */
+ * workgroups per CU, 5 = 4 with two 16-deep sub-tile buffers, 6 = 4 with two
+ * full-tile buffers at 2 workgroups per CU.  All variants compute bit-identical
+ * results; measured rates are in DESIGN.md. */
 int ntk_vgg_set_conv_variant(int variant);
 
 /* ------------------------------------------------------------------------

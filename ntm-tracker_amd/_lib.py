@@ -28,6 +28,7 @@ def _sig(lib):
         "ntk_vgg_set_conv_variant": (c_int, [c_int]),
         "ntk_vgg_pack_weights": (c_int, [P, P, c_int, c_int, P]),
         "ntk_vgg_conv3x3_relu_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+        "ntk_vgg_set_bf16_conv_variant": (c_int, [c_int]),
         "ntk_vgg_pack_weights_bf16": (c_int, [P, P, c_int, c_int, P]),
         "ntk_vgg_conv3x3_relu_bf16": (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
         "ntk_vgg_conv3x3_relu_f32_to_bf16": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),

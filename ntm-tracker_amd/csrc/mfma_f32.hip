@@ -304,12 +304,13 @@ __device__ __forceinline__ void lds_dma16(const float* src, float* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, bool POOL>
-__global__ __launch_bounds__(256, 4) void conv3x3_relu_dma_kernel(
+template <int BN, bool POOL, bool DB = false>
+__global__ __launch_bounds__(256, (DB ? 2 : 4)) void conv3x3_relu_dma_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
     constexpr int TN = BN / 64, NBI = BN / 32;      // B DMA instructions per wave
-    __shared__ __attribute__((aligned(1024))) float lds[(BM + BN) * BK];
+    constexpr int TILE = (BM + BN) * BK;
+    __shared__ __attribute__((aligned(1024))) float lds[(DB ? 2 : 1) * TILE];
     __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
 
     const int tid = threadIdx.x;
@@ -355,23 +356,177 @@ __global__ __launch_bounds__(256, 4) void conv3x3_relu_dma_kernel(
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int nk = Kp / BK;
-    for (int kt = 0; kt < nk; ++kt) {
+    auto issue = [&](int kt, float* Ad, float* Bd) {
         const int chunk = kt / 9, tap = kt - chunk * 9;
         const int c0 = chunk * BK;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        if (kt > 0) __syncthreads();                       // every wave has finished reading the previous tile
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int yy = ry[jj] + dy, xx = rx[jj] + dx;
             const bool ok = rpix[jj] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
             const float* src = ok ? in + (size_t)(rpix[jj] + dy * W + dx) * Cin + c0 + achunk[jj] : g_zero_page + (lane & 7) * 4;
-            lds_dma16(src, As + (wave * 4 + jj) * 8 * BK);
+            lds_dma16(src, Ad + (wave * 4 + jj) * 8 * BK);
         }
 #pragma unroll
-        for (int jj = 0; jj < NBI; ++jj) lds_dma16(bsrc[jj] + kt * BK, Bs + (wave * NBI + jj) * 8 * BK);
+        for (int jj = 0; jj < NBI; ++jj) lds_dma16(bsrc[jj] + kt * BK, Bd + (wave * NBI + jj) * 8 * BK);
+    };
+    if constexpr (!DB) {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt > 0) __syncthreads();                   // every wave has finished reading the previous tile
+            issue(kt, As, Bs);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                               // all four waves' DMA has landed
+            mma_ktile_swz<BN>(As, Bs, acc, wm, wn, lane);
+        }
+    } else {
+        issue(0, As, Bs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // all four waves' DMA has landed
-        mma_ktile_swz<BN>(As, Bs, acc, wm, wn, lane);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            float* Ac = lds + (kt & 1) * TILE;
+            float* An = lds + ((kt + 1) & 1) * TILE;
+            if (kt + 1 < nk) issue(kt + 1, An, An + BM * BK);
+            mma_ktile_swz<BN>(Ac, Ac + BM * BK, acc, wm, wn, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    const int kh = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn * (BN / 2) + tn * 32 + col;
+        const float bv = bias[n];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int mbase = wm * 64 + tm * 32 + 4 * kh;
+            if constexpr (!POOL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = s_pix[mbase + (r & 3) + 8 * (r >> 2)];
+                    if (pix >= 0) out[(size_t)pix * Cout + n] = fmaxf(acc[tm][tn][r] + bv, 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int pp = s_ppix[mbase + 8 * g];
+                    const float v = fmaxf(fmaxf(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1]),
+                                          fmaxf(acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
+                    if (pp >= 0) out[(size_t)pp * Cout + n] = fmaxf(v + bv, 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Variant 5: as variant 4, but the K-tile is split into two 16-deep sub-tiles held in TWO LDS buffers (still
+// 32 KB): the DMA of sub-tile s+1 is in flight while sub-tile s is multiplied, so no DMA latency is exposed and
+// there is ONE barrier per 32 MFMAs instead of two per 64 plus an exposed wait.  Rows are 64 B (4 chunks of
+// 16 B); chunk c of row r sits in slot c ^ ((r >> 2) & 3) (conflict-free ds_read_b128: 4 rows per 256-B bank
+// window x 4 slots); one DMA wave-instruction fills 16 rows.
+// ---------------------------------------------------------------------------
+constexpr int BKS = 16;
+
+template <int BN>
+__device__ __forceinline__ void mma_subtile_swz(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                f32x16 (&acc)[2][BN / 64], int wm, int wn, int lane) {
+    constexpr int TN = BN / 64;
+    const int i = lane & 31, kh = lane >> 5, f = (i >> 2) & 3;
+    const float* ap = As + (wm * 64 + i) * BKS;
+    const float* bp = Bs + (wn * (BN / 2) + i) * BKS;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int slot = ((2 * q + kh) ^ f) * 4;
+        f32x4 a[2], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(ap + tm * 32 * BKS + slot);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(bp + tn * 32 * BKS + slot);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+    }
+}
+
+template <int BN, bool POOL>
+__global__ __launch_bounds__(256, 4) void conv3x3_relu_dma2_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
+    constexpr int TN = BN / 64, NBI = BN / 64;      // B DMA instructions per wave and sub-tile
+    constexpr int SUB = (BM + BN) * BKS;            // floats per sub-tile buffer
+    __shared__ __attribute__((aligned(1024))) float lds[2 * SUB];
+    __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
+
+    const int tid = threadIdx.x;
+    const int ctiles = Cout / BN;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int rt = (li / ctiles) * 8 + xcd;
+    const int m0 = rt * BM;
+    const int n0 = (li % ctiles) * BN;
+    if (m0 >= npatch * 16) return;
+    if (tid < BM) {
+        ConvRowInfo ri = conv_row_info(m0 + tid, npatch, H, W);
+        s_pix[tid] = ri.pix; s_yx[tid] = ri.yx; s_ppix[tid] = ri.ppix;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // DMA roles: instruction jj of this wave fills rows (wave*2 + jj)*16 .. +15; lane -> (row = lane>>2, slot = lane&3)
+    const int lr = lane >> 2, slot = lane & 3;
+    const int schunk = (slot ^ ((lr >> 2) & 3)) * 4;        // source chunk (floats) of this lane's slot
+    int rpix[2], ry[2], rx[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int r = (wave * 2 + jj) * 16 + lr;
+        rpix[jj] = s_pix[r];
+        const int yx = s_yx[r];
+        ry[jj] = yx >> 16; rx[jj] = yx & 0xffff;
+    }
+    const float* bsrc[NBI];
+#pragma unroll
+    for (int jj = 0; jj < NBI; ++jj) bsrc[jj] = wp + (size_t)(n0 + (wave * NBI + jj) * 16 + lr) * Kp + schunk;
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    auto issue = [&](int st) {                              // DMA sub-tile st into buffer st & 1
+        float* As = lds + (st & 1) * SUB;
+        float* Bs = As + BM * BKS;
+        const int kt = st >> 1, half = st & 1;
+        const int chunk = kt / 9, tap = kt - chunk * 9;
+        const int c0 = chunk * BK + half * BKS;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int yy = ry[jj] + dy, xx = rx[jj] + dx;
+            const bool ok = rpix[jj] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const float* src = ok ? in + (size_t)(rpix[jj] + dy * W + dx) * Cin + c0 + schunk : g_zero_page + slot * 4;
+            lds_dma16(src, As + (wave * 2 + jj) * 16 * BKS);
+        }
+#pragma unroll
+        for (int jj = 0; jj < NBI; ++jj) lds_dma16(bsrc[jj] + kt * BK + half * BKS, Bs + (wave * NBI + jj) * 16 * BKS);
+    };
+
+    const int nst = 2 * (Kp / BK);
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) issue(st + 1);                    // lands in the other buffer while this one is multiplied
+        const float* As = lds + (st & 1) * SUB;
+        mma_subtile_swz<BN>(As, As + BM * BKS, acc, wm, wn, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
     const int kh = lane >> 5, col = lane & 31;
@@ -603,11 +758,23 @@ template <int BN, bool SMALLC>
 static void launch_conv(const float* in, const float* wp, const float* bias, float* out, int npatch,
                         int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
     if constexpr (!SMALLC) {
-        if (g_conv_variant == 4) {
+        if (g_conv_variant == 4 || g_conv_variant == 5) {
             const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
             dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
-            if (pool) conv3x3_relu_dma_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            else conv3x3_relu_dma_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+            if (g_conv_variant == 4) {
+                if (pool) conv3x3_relu_dma_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+                else conv3x3_relu_dma_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+            } else {
+                if (pool) conv3x3_relu_dma2_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+                else conv3x3_relu_dma2_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+            }
+            return;
+        }
+        if (g_conv_variant == 6) {
+            const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
+            dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
+            if (pool) conv3x3_relu_dma_kernel<BN, true, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+            else conv3x3_relu_dma_kernel<BN, false, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
             return;
         }
     }
@@ -621,7 +788,7 @@ static void launch_conv(const float* in, const float* wp, const float* bias, flo
 }
 
 extern "C" int ntk_vgg_set_conv_variant(int v) {
-    NTK_REQUIRE(v >= 0 && v <= 4, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d", v);
+    NTK_REQUIRE(v >= 0 && v <= 6, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d", v);
     g_conv_variant = v;
     return NTK_OK;
 }

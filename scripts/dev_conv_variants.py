@@ -14,7 +14,7 @@ for name, H, cin, cout, pool in layers:
     b = torch.zeros(cout, device=dev); wp = vgg.pack_weights(w)
     ref = None; res = {}
     for rnd in range(3):
-        for v in (2, 4):
+        for v in (4, 6):
             L.ntk_vgg_set_conv_variant(v)
             y = vgg.conv3x3_relu(x, wp, b, cin, cout, fuse_pool=pool); torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
