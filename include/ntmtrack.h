@@ -206,6 +206,18 @@ int ntk_gather_serialize(const float* fmap, const float* gts0, float* X, int B, 
                          int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
                          int grid_n, void* stream);
 
+/* inference serialisation (quirk Q8, test_tracker.py:400-404): the delimiter row comes FIRST */
+int ntk_gather_serialize_online(const float* fmap, const float* gts0, float* X, int B, int T,
+                                int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
+                                int grid_n, void* stream);
+
+/* tf.image.crop_and_resize (bilinear, one normalised box y1,x1,y2,x2, extrapolation value) of (image - mean):
+ * image [H,W,C] fp32, mean [C] (nullable) -> out [crop_h,crop_w,C]
+ * replaces: test_tracker.py:344-352 (online) / direct_offset_output.py:207-211 (training input pipeline) */
+int ntk_crop_and_resize(const float* image, int H, int W, int C, const float* mean, float y1, float x1,
+                        float y2, float x2, float* out, int crop_h, int crop_w, float extrapolation,
+                        void* stream);
+
 /* output gather + tanh + l2 loss (:581-606) and its gradient:
  * pred [B,T-1,O] (nullable), loss [1], dlogits [B,S,O] (nullable). */
 int ntk_offset_loss(const float* logits, const float* offsets, float* pred, float* loss,

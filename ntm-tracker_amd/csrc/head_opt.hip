@@ -11,10 +11,13 @@ namespace {
 // one 128-thread workgroup per serialised row (b, t, i), i in [0, NF]; row i == NF is the delimiter
 __global__ void gather_serialize_kernel(const float* __restrict__ fmap, const float* __restrict__ gts0,
                                         float* __restrict__ X, int T, int Hf, int Wf, int C, int ldx,
-                                        int g0, int gstep, int gn) {
+                                        int g0, int gstep, int gn, int delim_first) {
     const int NF = gn * gn;
-    const int row = blockIdx.x;               // (b*T + t)*(NF+1) + i
-    const int i = row % (NF + 1);
+    const int row = blockIdx.x;               // (b*T + t)*(NF+1) + position
+    const int pos = row % (NF + 1);
+    // training order: 64 feature rows then the delimiter (direct_offset_output.py:480-481);
+    // inference order (quirk Q8): the delimiter row FIRST (test_tracker.py:400-404)
+    const int i = delim_first ? (pos == 0 ? NF : pos - 1) : pos;
     const int ft = row / (NF + 1);            // b*T + t
     const int t = ft % T, b = ft / T;
     float* xr = X + (size_t)row * ldx;
@@ -174,9 +177,9 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int ntk_gather_serialize(const float* fmap, const float* gts0, float* X, int B, int T,
-                                    int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
-                                    int grid_n, void* stream) {
+static int gather_serialize_impl(const float* fmap, const float* gts0, float* X, int B, int T,
+                                 int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
+                                 int grid_n, int delim_first, void* stream) {
     NTK_REQUIRE(fmap && X, NTK_ERR_BAD_PTR, "ntk_gather_serialize: null pointer");
     NTK_REQUIRE(ntk_aligned16(fmap) && ntk_aligned16(X), NTK_ERR_BAD_PTR, "ntk_gather_serialize: 16-byte alignment");
     NTK_REQUIRE(B > 0 && T > 0 && C > 0 && (C % 4) == 0 && ldx >= C + 2 && (ldx % 4) == 0 && grid_n > 0 &&
@@ -187,8 +190,58 @@ extern "C" int ntk_gather_serialize(const float* fmap, const float* gts0, float*
     const long rows = (long)B * T * (grid_n * grid_n + 1);
     NTK_REQUIRE(rows < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_gather_serialize: too many rows");
     gather_serialize_kernel<<<(unsigned)rows, 128, 0, (hipStream_t)stream>>>(fmap, gts0, X, T, Hf, Wf, C, ldx,
-                                                                            grid_start, grid_step, grid_n);
+                                                                            grid_start, grid_step, grid_n, delim_first);
     NTK_CHECK_LAUNCH("ntk_gather_serialize");
+    return NTK_OK;
+}
+
+extern "C" int ntk_gather_serialize(const float* fmap, const float* gts0, float* X, int B, int T,
+                                    int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
+                                    int grid_n, void* stream) {
+    return gather_serialize_impl(fmap, gts0, X, B, T, Hf, Wf, C, ldx, grid_start, grid_step, grid_n, 0, stream);
+}
+
+extern "C" int ntk_gather_serialize_online(const float* fmap, const float* gts0, float* X, int B, int T,
+                                           int Hf, int Wf, int C, int ldx, int grid_start, int grid_step,
+                                           int grid_n, void* stream) {
+    return gather_serialize_impl(fmap, gts0, X, B, T, Hf, Wf, C, ldx, grid_start, grid_step, grid_n, 1, stream);
+}
+
+// tf.image.crop_and_resize (bilinear, one box) of (image - mean): out[y][x][c], extrapolation outside the image
+__global__ void crop_resize_kernel(const float* __restrict__ img, int H, int W, int C, const float* __restrict__ mean,
+                                   float y1, float x1, float y2, float x2, float* __restrict__ out, int ch, int cw,
+                                   float extrapolation) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ch * cw * C) return;
+    const int c = idx % C, x = (idx / C) % cw, y = idx / (C * cw);
+    const float hs = (ch > 1) ? (y2 - y1) * (float)(H - 1) / (float)(ch - 1) : 0.f;
+    const float wsc = (cw > 1) ? (x2 - x1) * (float)(W - 1) / (float)(cw - 1) : 0.f;
+    const float in_y = (ch > 1) ? y1 * (float)(H - 1) + (float)y * hs : 0.5f * (y1 + y2) * (float)(H - 1);
+    const float in_x = (cw > 1) ? x1 * (float)(W - 1) + (float)x * wsc : 0.5f * (x1 + x2) * (float)(W - 1);
+    float v = extrapolation;
+    if (in_y >= 0.f && in_y <= (float)(H - 1) && in_x >= 0.f && in_x <= (float)(W - 1)) {
+        const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+        const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+        const float yl = in_y - (float)ty, xl = in_x - (float)lx;
+        const float m = mean ? mean[c] : 0.f;
+        const float tl = img[((size_t)ty * W + lx) * C + c] - m, tr = img[((size_t)ty * W + rx) * C + c] - m;
+        const float bl = img[((size_t)by * W + lx) * C + c] - m, br = img[((size_t)by * W + rx) * C + c] - m;
+        const float top = tl + (tr - tl) * xl, bot = bl + (br - bl) * xl;
+        v = top + (bot - top) * yl;
+    }
+    out[idx] = v;
+}
+
+extern "C" int ntk_crop_and_resize(const float* image, int H, int W, int C, const float* mean, float y1, float x1,
+                                   float y2, float x2, float* out, int crop_h, int crop_w, float extrapolation,
+                                   void* stream) {
+    NTK_REQUIRE(image && out, NTK_ERR_BAD_PTR, "ntk_crop_and_resize: null pointer");
+    NTK_REQUIRE(H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0, NTK_ERR_BAD_SHAPE,
+                "ntk_crop_and_resize: H=%d W=%d C=%d crop=%dx%d", H, W, C, crop_h, crop_w);
+    const int total = crop_h * crop_w * C;
+    crop_resize_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(image, H, W, C, mean, y1, x1, y2, x2, out,
+                                                                             crop_h, crop_w, extrapolation);
+    NTK_CHECK_LAUNCH("ntk_crop_and_resize");
     return NTK_OK;
 }
 
