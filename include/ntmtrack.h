@@ -218,6 +218,9 @@ int ntk_crop_and_resize(const float* image, int H, int W, int C, const float* me
                         float y2, float x2, float* out, int crop_h, int crop_w, float extrapolation,
                         void* stream);
 
+/* tf.image.resize_images(img, [out_h, out_w]) (bilinear, TF-1 defaults) -- direct_offset_output.py:193 */
+int ntk_resize_bilinear(const float* image, int H, int W, int C, float* out, int out_h, int out_w, void* stream);
+
 /* output gather + tanh + l2 loss (:581-606) and its gradient:
  * pred [B,T-1,O] (nullable), loss [1], dlogits [B,S,O] (nullable). */
 int ntk_offset_loss(const float* logits, const float* offsets, float* pred, float* loss,

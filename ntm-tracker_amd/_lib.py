@@ -45,6 +45,7 @@ def _sig(lib):
         "ntk_gather_serialize": (c_int, [P, P, P] + [c_int] * 9 + [P]),
         "ntk_gather_serialize_online": (c_int, [P, P, P] + [c_int] * 9 + [P]),
         "ntk_crop_and_resize": (c_int, [P, c_int, c_int, c_int, P] + [ctypes.c_float] * 4 + [P, c_int, c_int, ctypes.c_float, P]),
+        "ntk_resize_bilinear": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P]),
         "ntk_offset_loss": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_log_loss": (c_int, [P, P, P, P, c_int, P]),
         "ntk_ntm_init_state": (c_int, [P, P, c_int, c_int, c_int, P]),

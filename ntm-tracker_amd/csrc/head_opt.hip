@@ -232,6 +232,32 @@ __global__ void crop_resize_kernel(const float* __restrict__ img, int H, int W, 
     out[idx] = v;
 }
 
+// tf.image.resize_images(..., BILINEAR) with TF-1 defaults (align_corners=False, no half-pixel centres):
+// src = dst * (in / out); neighbours floor(src) and min(floor(src)+1, in-1)
+__global__ void resize_bilinear_kernel(const float* __restrict__ img, int H, int W, int C, float* __restrict__ out,
+                                       int OH, int OW) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)OH * OW * C) return;
+    const int c = (int)(idx % C), x = (int)((idx / C) % OW), y = (int)(idx / ((size_t)C * OW));
+    const float sy = (float)y * ((float)H / (float)OH), sx = (float)x * ((float)W / (float)OW);
+    const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    const float tl = img[((size_t)y0 * W + x0) * C + c], tr = img[((size_t)y0 * W + x1) * C + c];
+    const float bl = img[((size_t)y1 * W + x0) * C + c], br = img[((size_t)y1 * W + x1) * C + c];
+    const float top = tl + (tr - tl) * fx, bot = bl + (br - bl) * fx;
+    out[idx] = top + (bot - top) * fy;
+}
+
+extern "C" int ntk_resize_bilinear(const float* image, int H, int W, int C, float* out, int out_h, int out_w, void* stream) {
+    NTK_REQUIRE(image && out, NTK_ERR_BAD_PTR, "ntk_resize_bilinear: null pointer");
+    NTK_REQUIRE(H > 0 && W > 0 && C > 0 && out_h > 0 && out_w > 0, NTK_ERR_BAD_SHAPE, "ntk_resize_bilinear: %dx%dx%d -> %dx%d", H, W, C, out_h, out_w);
+    const size_t total = (size_t)out_h * out_w * C;
+    resize_bilinear_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(image, H, W, C, out, out_h, out_w);
+    NTK_CHECK_LAUNCH("ntk_resize_bilinear");
+    return NTK_OK;
+}
+
 extern "C" int ntk_crop_and_resize(const float* image, int H, int W, int C, const float* mean, float y1, float x1,
                                    float y2, float x2, float* out, int crop_h, int crop_w, float extrapolation,
                                    void* stream) {
