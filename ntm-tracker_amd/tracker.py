@@ -68,6 +68,33 @@ class RMSPropClip(object):
         self.global_step += 1
 
 
+class _Checkpointing(object):
+    """Save / restore of parameters + optimiser slots + global_step (the role of tf.train.Saver in the reference,
+    direct_offset_output.py:260-267, :329-333: save at validation intervals, restore from --ckpt_path after init).
+    TF checkpoints themselves are not readable here (none ship with the reference); parameters can be imported
+    from / exported to the reference's variable names with load_state_dict() / state_dict()."""
+
+    def _ckpt_params(self):
+        raise NotImplementedError
+
+    def save_checkpoint(self, path):
+        P = self._ckpt_params()
+        torch.save({"format": "ntmtrack-ckpt-1", "kind": type(self).__name__, "numel": P.numel,
+                    "params": P.flat.detach().cpu(), "ms": self.opt.ms.detach().cpu(), "mom": self.opt.mom.detach().cpu(),
+                    "global_step": int(self.opt.global_step)}, path)
+        return path
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        P = self._ckpt_params()
+        if ck.get("format") != "ntmtrack-ckpt-1" or ck.get("kind") != type(self).__name__ or ck.get("numel") != P.numel:
+            raise _lib.NtkError("checkpoint %s does not match this tracker (%s, %d parameters)" % (path, type(self).__name__, P.numel))
+        P.flat.copy_(ck["params"].to(P.flat.device))
+        self.opt.ms.copy_(ck["ms"].to(P.flat.device))
+        self.opt.mom.copy_(ck["mom"].to(P.flat.device))
+        self.opt.global_step = int(ck["global_step"])
+
+
 class _TwoStreamPipeline(object):
     """Two-stage software pipeline shared by the trackers: the frozen VGG trunk of batch i+1 runs on its own
     HIP stream while the recurrent core's forward / BPTT / optimiser of batch i runs on a high-priority stream."""
@@ -127,7 +154,7 @@ class _TwoStreamPipeline(object):
             cur.wait_stream(self._s_ntm)
 
 
-class NTMOffsetTracker(_TwoStreamPipeline):
+class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     """VGG-16 conv4_3 + NTMCell offsets tracker, defaults from direct_offset_output.py:21-42."""
 
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
@@ -178,6 +205,9 @@ class NTMOffsetTracker(_TwoStreamPipeline):
     def _flat_grad(self):
         return self.cell.params.grad
 
+    def _ckpt_params(self):
+        return self.cell.params
+
     def train_step(self, frames, gts0, offsets):
         """VGG forward, NTM forward + BPTT, gradient all-reduce (if distributed), clip + RMSProp.
         Returns the (local) loss as a 1-element device tensor."""
@@ -188,7 +218,7 @@ class NTMOffsetTracker(_TwoStreamPipeline):
         return loss
 
 
-class DNCOffsetTracker(_TwoStreamPipeline):
+class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     """VGG-16 conv4_3 + DNC core offsets tracker (direct_offset_output_with_dnc.py:408-648), forward path:
     frames -> VGG -> 64-point gather + serialise -> time-major dynamic_rnn over dnc.DNC (clip_value 20)
     -> output gather at the delimiter steps -> tanh.  Defaults from :22-43 (mem 128x20, R4/W1, hidden 200)."""
@@ -211,6 +241,9 @@ class DNCOffsetTracker(_TwoStreamPipeline):
 
     def _flat_grad(self):
         return self.core.params.grad
+
+    def _ckpt_params(self):
+        return self.core.params
 
     def forward_features(self, fmap, gts0, record=False):
         """-> logits [B,S,2] (batch-major view of the time-major core output, _with_dnc.py:534-541)."""

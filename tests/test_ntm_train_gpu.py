@@ -132,3 +132,29 @@ def test_train_step_matches_oracle_update(cuda):
         err = np.max(np.abs(got[k].numpy().astype(np.float64) - new_ref[k]))
         # fp32 storage of the parameter (|p| <= 0.3 -> half an ulp = 1.5e-8) plus 0.5 % of the step
         assert err <= 3e-8 + 5e-3 * np.max(np.abs(delta_ref)), "%s: %.3e (step %.3e)" % (k, err, np.max(np.abs(delta_ref)))
+
+
+def test_checkpoint_roundtrip_resumes_bit_identically(cuda, tmp_path):
+    """save after step 1, keep training to step 3; a fresh tracker restored from the checkpoint reaches the same
+    parameters bit for bit (parameters, RMSProp slots and global_step all restored)."""
+    from ntmtrack import tracker
+    B, T = 2, 2
+    g = torch.Generator().manual_seed(1)
+    fmap = torch.relu(torch.randn((B * T, 28, 28, 512), generator=g)).to(cuda)
+    gts0 = torch.rand((B, 64), generator=g).to(cuda)
+    offs = (torch.rand((B, T, 2), generator=g) - 0.5).to(cuda)
+    a = tracker.NTMOffsetTracker(B, T, vgg_weights=None, device=cuda, seed=3, learning_rate=1e-2)
+    a.loss_and_grads(fmap, gts0, offs); a.opt.step()
+    path = a.save_checkpoint(str(tmp_path / "ck.pt"))
+    for _ in range(2):
+        a.loss_and_grads(fmap, gts0, offs); a.opt.step()
+    b = tracker.NTMOffsetTracker(B, T, vgg_weights=None, device=cuda, seed=99, learning_rate=1e-2)
+    b.load_checkpoint(path)
+    assert b.opt.global_step == 1
+    for _ in range(2):
+        b.loss_and_grads(fmap, gts0, offs); b.opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.cell.params.flat, b.cell.params.flat) and torch.equal(a.opt.ms, b.opt.ms)
+    d = tracker.DNCOffsetTracker(B, T, vgg_weights=None, mem_size=32, mem_dim=16, hidden_size=32, device=cuda)
+    with pytest.raises(Exception):
+        d.load_checkpoint(path)                      # wrong tracker kind is refused
