@@ -30,14 +30,28 @@ void ntk_set_error(const char* fmt, ...);
 
 static inline bool ntk_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
-// wave64 reductions
+// wave64 reductions on the DPP data path (no LDS crossbar traffic): butterfly inside each row of 16 lanes with
+// quad_perm / row_half_mirror / row_mirror, then the four row totals are read with v_readlane.  The result is
+// wave-uniform.  (__shfl_xor lowers to ds_bpermute_b32 on gfx950: ~5x the latency per step.)
+template <int CTRL>
+__device__ __forceinline__ float ntk_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += ntk_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += ntk_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += ntk_dpp<0x141>(v);    // row_half_mirror
+    v += ntk_dpp<0x140>(v);    // row_mirror
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, ntk_dpp<0xB1>(v));
+    v = fmaxf(v, ntk_dpp<0x4E>(v));
+    v = fmaxf(v, ntk_dpp<0x141>(v));
+    v = fmaxf(v, ntk_dpp<0x140>(v));
+    const int b = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
 }
