@@ -53,7 +53,7 @@ static inline void ntm_fill_dims(NtmDims& d, int B, int S, int N, int Md, int R,
 
 // LDS carve-up shared by forward and backward (offsets in floats)
 struct NtmLds {
-    int part, M, W, Wg, Z, C, U, Ks, Cn, CnPart, Sw, Red, total;
+    int part, M, W, Wg, Z, C, U, Ks, Cn, Pw, total;
 };
 
 static inline __host__ __device__ int ntm_imax(int a, int b) { return a > b ? a : b; }

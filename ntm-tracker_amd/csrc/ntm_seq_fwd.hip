@@ -8,12 +8,12 @@
 // Per step (all phases separated by workgroup barriers):
 //   P1 gate partials      z=[read_prev;h_prev] (K) x Wr[K][4*hid]   (K-sliced over thread groups)
 //   P2 LSTM cell          BasicLSTMCell, gate order i,j,f,o, forget_bias 0 (ntm_cell.py:45-50)
-//                         + column sum-of-squares partials of M for quirk Q1
+//                         || the other waves l2-normalise the feature columns of M over the slots (quirk Q1)
 //   P3 unpack partials    h' x Wa[hid][PP]                           (ntm_cell.py:124-126, :220)
 //   P4 control activations tanh/softplus/sigmoid/1+softplus           (:133,140,151,169,193,195)
-//   P5 key scaling, shift softmax, output softmax                     (ops.py:150-152, ntm_cell.py:161,221)
-//   P6 similarity (Q1: feature columns normalised over slots), beta, softmax over N, gate (:136-156)
-//   P7 circular shift with taps -(r+1)..r-1 (Q2), sharpen with +1e-3 (Q4)   (ops.py:204-213, ntm_cell.py:173-176)
+//   P5-P7 ONE WAVE PER HEAD, no workgroup barrier: key scaling, shift softmax (ops.py:150-152, ntm_cell.py:161),
+//      similarity (Q1: feature columns normalised over slots), beta, softmax over N, gate (:136-156),
+//      circular shift with taps -(r+1)..r-1 (Q2), sharpen with +1e-3 (Q4)   (ops.py:204-213, ntm_cell.py:173-176)
 //   P8 erase/add write and read (reads see the pre-write memory unless write_first, Q6) (:202-215)
 #include "ntm_common.h"
 
@@ -54,7 +54,6 @@ static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
     const int nslB = ntm_imin(ntm_imax(1, T / ncg), d.hid);
     const int RM = d.R * d.Md;
     const int nslR = ntm_imin(ntm_imax(1, T / RM), d.N);
-    const int nslC = ntm_imax(1, (T - d.hid) / d.Md);
     int o = 0;
     L.part = o; o += ntm_align4(ntm_imax(ntm_imax(nsl * 4 * d.hid, nslB * d.PP), nslR * RM));
     L.M = o; o += ntm_align4(d.N * MP);
@@ -65,9 +64,7 @@ static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
     L.U = o; o += ntm_align4(d.PP);
     L.Ks = o; o += ntm_align4(d.H * d.Md);
     L.Cn = o; o += ntm_align4(d.Md);
-    L.CnPart = o; o += ntm_align4(nslC * d.Md);
-    L.Sw = o; o += ntm_align4(d.H * d.SS);
-    L.Red = o; o += ntm_align4(d.H * d.N);
+    L.Pw = o; o += ntm_align4(d.H * d.N);
     L.total = o;
 }
 
@@ -100,7 +97,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
     float* sU = smem + L.U;
     float* sKs = smem + L.Ks;
     float* sCn = smem + L.Cn;
-    float* sPw = smem + L.Red;             // [H][N] sharpened weights before normalisation
+    float* sPw = smem + L.Pw;              // [H][N] sharpened weights before normalisation
 
     // work decomposition (uniform per kernel)
     const int nsl = max(1, T / hid);                 // K-slices of the gate product

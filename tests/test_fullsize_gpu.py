@@ -73,3 +73,26 @@ def test_training_step_is_bitwise_deterministic(cuda):
     torch.cuda.synchronize()
     assert torch.equal(grads[0], grads[1]) and torch.equal(params[0], params[1])
     assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+
+
+def test_config4_shape_training_step_properties(cuda):
+    """BASELINE config 4's per-GPU shape (64 sequences x 30 frames -> 1950 strictly sequential steps): the whole
+    NTM training step runs, is finite, batch-invariant and deterministic; doubling the batch by repeating the
+    sequences doubles the (un-normalised, summed) loss and gradient exactly as direct_offset_output.py:606 implies --
+    the property the data-parallel all-reduce relies on."""
+    from ntmtrack import tracker
+    B, T = 64, 30
+    g = torch.Generator().manual_seed(9)
+    fmap_h = torch.relu(torch.randn((B // 2 * T, 28, 28, 512), generator=g)).to(cuda)
+    gts_h = torch.rand((B // 2, 64), generator=g).to(cuda)
+    offs_h = (torch.rand((B // 2, T, 2), generator=g) - 0.5).to(cuda)
+    half = tracker.NTMOffsetTracker(B // 2, T, vgg_weights=None, device=cuda, seed=6)
+    loss_h, _ = half.loss_and_grads(fmap_h, gts_h, offs_h)
+    full = tracker.NTMOffsetTracker(B, T, vgg_weights=None, device=cuda, seed=6)
+    loss_f, _ = full.loss_and_grads(torch.cat([fmap_h, fmap_h]), torch.cat([gts_h, gts_h]), torch.cat([offs_h, offs_h]))
+    torch.cuda.synchronize()
+    assert torch.isfinite(full.cell.params.grad).all()
+    np.testing.assert_allclose(float(loss_f.cpu()), 2 * float(loss_h.cpu()), rtol=1e-5)
+    gh, gf = half.cell.params.grad, full.cell.params.grad
+    rel = float((gf - 2 * gh).abs().max() / gf.abs().max())
+    assert rel < 1e-4, rel
