@@ -178,6 +178,20 @@ int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, f
                     float* rec_cr, float* rec_al, float* rec_p, float* rec_fwd, float* rec_bwd,
                     float* rec_M, float* rec_L, float* rec_ypre, void* stream);
 
+/* Stand-alone DNC addressing modules (dnc/addressing.py), the module-level API the reference's own tests call:
+ * CosineWeights._build (:83-105), TemporalLinkage._build (:133-153) and directional_read_weights (:155-181),
+ * Freeness._build (:279-305) and write_allocation_weights (:307-340; one head: _allocation :376-405). */
+int ntk_dnc_cosine_weights(const float* memory, const float* keys, const float* strengths, float* out,
+                           int B, int N, int W, int H, void* stream);
+int ntk_dnc_linkage(const float* prev_link, const float* prev_prec, const float* write_weights, float* link,
+                    float* prec, int B, int N, int Wn, void* stream);
+int ntk_dnc_directional_read_weights(const float* link, const float* prev_read_weights, float* out, int B, int N,
+                                     int Wn, int R, int forward, void* stream);
+int ntk_dnc_freeness(const float* write_weights, const float* free_gate, const float* read_weights,
+                     const float* prev_usage, float* usage, int B, int N, int Wn, int R, void* stream);
+int ntk_dnc_write_allocation_weights(const float* usage, const float* write_gates, float* out, int B, int N, int Wn,
+                                     void* stream);
+
 /* Full BPTT through a recorded DNC sequence (num_writes == 1).  WrT [4*hid][ldkT], WiT [IP][ldhT]
  * are transposed copies of Wr / Wi; *0 pointers are the state BEFORE step 0; gM [B,N,W] and
  * gL [B,N,N] are zero-initialised scratch.  Out: raw gate gradients dgates [B,S,4*hid], raw

@@ -272,3 +272,93 @@ def run_model(input_sequence, output_size, core=None, **flags):
                    device=input_sequence.device)
     out, _ = core.run_sequence(input_sequence, core.initial_state(input_sequence.shape[1]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Stand-alone addressing modules (dnc/addressing.py) with the reference's constructor arguments and call
+# signatures; forward only (training goes through the fused core above).
+# ---------------------------------------------------------------------------------------------------------
+def _f32(t, dev):
+    return torch.as_tensor(t, dtype=torch.float32).to(dev).contiguous()
+
+
+class CosineWeights(object):
+    """addressing.py:59-105: CosineWeights(num_heads, word_size)(memory [B,N,W], keys [B,H,W], strengths [B,H]) -> [B,H,N]
+    (strength_op is softplus, the reference default)."""
+
+    def __init__(self, num_heads, word_size, name="cosine_weights", device="cuda"):
+        self._num_heads, self._word_size, self.device = num_heads, word_size, torch.device(device)
+
+    def __call__(self, memory, keys, strengths):
+        m, k, s = _f32(memory, self.device), _f32(keys, self.device), _f32(strengths, self.device)
+        B, N, W = m.shape
+        H = k.shape[1]
+        out = torch.empty((B, H, N), device=self.device)
+        _lib.check(_lib.lib().ntk_dnc_cosine_weights(_P(m), _P(k), _P(s), _P(out), B, N, W, H, _lib.stream()), "ntk_dnc_cosine_weights")
+        return out
+
+
+class TemporalLinkage(object):
+    """addressing.py:108-249: TemporalLinkage(memory_size, num_writes)(write_weights, prev_state) -> TemporalLinkageState;
+    directional_read_weights(link, prev_read_weights, forward) -> [B,R,Wn,N]."""
+
+    def __init__(self, memory_size, num_writes, name="temporal_linkage", device="cuda"):
+        self._memory_size, self._num_writes, self.device = memory_size, num_writes, torch.device(device)
+
+    def __call__(self, write_weights, prev_state):
+        ww = _f32(write_weights, self.device)
+        pl, pp = _f32(prev_state.link, self.device), _f32(prev_state.precedence_weights, self.device)
+        B, Wn, N = ww.shape
+        link, prec = torch.empty_like(pl), torch.empty_like(pp)
+        _lib.check(_lib.lib().ntk_dnc_linkage(_P(pl), _P(pp), _P(ww), _P(link), _P(prec), B, N, Wn, _lib.stream()), "ntk_dnc_linkage")
+        return TemporalLinkageState(link=link, precedence_weights=prec)
+
+    def directional_read_weights(self, link, prev_read_weights, forward):
+        L, rw = _f32(link, self.device), _f32(prev_read_weights, self.device)
+        B, Wn, N, _ = L.shape
+        R = rw.shape[1]
+        out = torch.empty((B, R, Wn, N), device=self.device)
+        _lib.check(_lib.lib().ntk_dnc_directional_read_weights(_P(L), _P(rw), _P(out), B, N, Wn, R, 1 if forward else 0,
+                                                               _lib.stream()), "ntk_dnc_directional_read_weights")
+        return out
+
+    @property
+    def state_size(self):
+        return TemporalLinkageState((self._num_writes, self._memory_size, self._memory_size), (self._num_writes, self._memory_size))
+
+
+class Freeness(object):
+    """addressing.py:252-410: Freeness(memory_size)(write_weights, free_gate, read_weights, prev_usage) -> usage;
+    write_allocation_weights(usage, write_gates, num_writes) -> [B,Wn,N]."""
+
+    def __init__(self, memory_size, name="freeness", device="cuda"):
+        self._memory_size, self.device = memory_size, torch.device(device)
+
+    def __call__(self, write_weights, free_gate, read_weights, prev_usage):
+        ww, fg = _f32(write_weights, self.device), _f32(free_gate, self.device)
+        rw, pu = _f32(read_weights, self.device), _f32(prev_usage, self.device)
+        B, Wn, N = ww.shape
+        usage = torch.empty_like(pu)
+        _lib.check(_lib.lib().ntk_dnc_freeness(_P(ww), _P(fg), _P(rw), _P(pu), _P(usage), B, N, Wn, rw.shape[1], _lib.stream()),
+                   "ntk_dnc_freeness")
+        return usage
+
+    def write_allocation_weights(self, usage, write_gates, num_writes):
+        u, g = _f32(usage, self.device), _f32(write_gates, self.device)
+        B, N = u.shape
+        out = torch.empty((B, num_writes, N), device=self.device)
+        _lib.check(_lib.lib().ntk_dnc_write_allocation_weights(_P(u), _P(g), _P(out), B, N, num_writes, _lib.stream()),
+                   "ntk_dnc_write_allocation_weights")
+        return out
+
+    def _allocation(self, usage):
+        u = _f32(usage, self.device)
+        B, N = u.shape
+        out = torch.empty((B, 1, N), device=self.device)
+        _lib.check(_lib.lib().ntk_dnc_write_allocation_weights(_P(u), None, _P(out), B, N, 1, _lib.stream()),
+                   "ntk_dnc_write_allocation_weights")
+        return out[:, 0]
+
+    @property
+    def state_size(self):
+        return (self._memory_size,)
