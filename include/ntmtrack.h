@@ -196,7 +196,10 @@ int ntk_dnc_write_allocation_weights(const float* usage, const float* write_gate
  * are transposed copies of Wr / Wi; *0 pointers are the state BEFORE step 0; gM [B,N,W] and
  * gL [B,N,N] are zero-initialised scratch.  Out: raw gate gradients dgates [B,S,4*hid], raw
  * interface gradients dxi [B,S,IP], gradient of the pre-clip output dypre [B,S,OP]; weight
- * gradients follow as ntk_gemm_tn_f32 over the recorded rows. */
+ * gradients follow as ntk_gemm_tn_f32 over the recorded rows.
+ * Segmented BPTT (long sequences, config 5): run the segments last to first, re-recording each from its
+ * checkpointed state; gM / gL are NOT re-zeroed between segments and gcarry [B, 2N + R*N + ldkT + hid]
+ * (optional, may be null) carries the remaining state gradients: read when carry_in != 0, always written. */
 int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value,
                     const float* WrT, int ldkT, const float* WiT, int ldhT, const float* Wy,
                     const float* mem0, const float* link0, const float* usage0, const float* rw0,
@@ -206,7 +209,7 @@ int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, f
                     const float* rec_al, const float* rec_p, const float* rec_fwd, const float* rec_bwd,
                     const float* rec_M, const float* rec_L, const float* rec_ypre,
                     const float* dout, float* gM, float* gL, float* dgates, float* dxi, float* dypre,
-                    void* stream);
+                    float* gcarry, int carry_in, void* stream);
 
 /* ------------------------------------------------------------------------
  * tracking head (direct_offset_output.py)

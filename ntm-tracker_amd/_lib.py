@@ -46,7 +46,7 @@ def _sig(lib):
         "ntk_dnc_directional_read_weights": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
         "ntk_dnc_freeness": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_dnc_write_allocation_weights": (c_int, [P, P, P, c_int, c_int, c_int, P]),
-        "ntk_dnc_seq_bwd": (c_int, [c_int] * 8 + [ctypes.c_float] + [P, c_int, P, c_int, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P]),
+        "ntk_dnc_seq_bwd": (c_int, [c_int] * 8 + [ctypes.c_float] + [P, c_int, P, c_int, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P, c_int, P]),
         "ntk_gather_serialize": (c_int, [P, P, P] + [c_int] * 9 + [P]),
         "ntk_gather_serialize_online": (c_int, [P, P, P] + [c_int] * 9 + [P]),
         "ntk_crop_and_resize": (c_int, [P, c_int, c_int, c_int, P] + [ctypes.c_float] * 4 + [P, c_int, c_int, ctypes.c_float, P]),

@@ -30,11 +30,12 @@ struct DncBwdArgs {
     const float* dout;               // [B,S,O]
     float* gM; float* gL;            // [B,N,W], [B,N,N] zero-initialised scratch (carried gradients)
     float* dgates; float* dxi; float* dypre;
+    float* gcarry; int carry_in;     // [B, 2N + R*N + ldkT + hid] gradients carried into state t=-1 (segmented BPTT)
 };
 
 struct DncBwdLds {
     int part, I, DX, WW, WWp, U, Up, Pp, CW, AL, NM, NMw, SIMw, DWW, DCW, DA, gP, DPp, gU, gUn,
-        RW, RWp, CR, FV, BV, gRW, DRW, DF, DB, DSIM, SIMr, DRWp, GZ, DR, DKR, DKW, DE, DV, DHC, gC, DG, SC, total;
+        RWp, CR, gRW, DRW, DF, DB, DSIM, SIMr, DRWp, GZ, DR, DKR, DKW, DE, DV, DHC, gC, DG, SC, total;
 };
 
 static void dnc_bwd_lds(const DncDims& d, int ldkT, int ldhT, DncBwdLds& L) {
@@ -52,7 +53,7 @@ static void dnc_bwd_lds(const DncDims& d, int ldkT, int ldhT, DncBwdLds& L) {
     L.WW = take(N); L.WWp = take(N); L.U = take(N); L.Up = take(N); L.Pp = take(N); L.CW = take(N); L.AL = take(N);
     L.NM = take(N); L.NMw = take(N); L.SIMw = take(N); L.DWW = take(N); L.DCW = take(N); L.DA = take(N);
     L.gP = take(N); L.DPp = take(N); L.gU = take(N); L.gUn = take(N);
-    L.RW = take(RN); L.RWp = take(RN); L.CR = take(RN); L.FV = take(RN); L.BV = take(RN); L.gRW = take(RN);
+    L.RWp = take(RN); L.CR = take(RN); L.gRW = take(RN);
     L.DRW = take(RN); L.DF = take(RN); L.DB = take(RN); L.DSIM = take(RN); L.SIMr = take(RN); L.DRWp = take(RN);
     L.GZ = take(ldkT); L.DR = take(RWd); L.DKR = take(RWd); L.DKW = take(d.W); L.DE = take(d.W); L.DV = take(d.W);
     L.DHC = take(d.hid); L.gC = take(d.hid); L.DG = take(4 * d.hid); L.SC = take(64);
@@ -73,8 +74,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_bwd_kernel(DncBwdArgs a, DncBwdLds
     float* sNMw = smem + L.NMw; float* sSIMw = smem + L.SIMw; float* sDWW = smem + L.DWW; float* sDCW = smem + L.DCW;
     float* sDA = smem + L.DA;   float* sgP = smem + L.gP;   float* sDPp = smem + L.DPp; float* sgU = smem + L.gU;
     float* sgUn = smem + L.gUn;
-    float* sRW = smem + L.RW;   float* sRWp = smem + L.RWp; float* sCR = smem + L.CR; float* sFV = smem + L.FV;
-    float* sBV = smem + L.BV;   float* sgRW = smem + L.gRW; float* sDRW = smem + L.DRW; float* sDF = smem + L.DF;
+    float* sRWp = smem + L.RWp; float* sCR = smem + L.CR; float* sgRW = smem + L.gRW; float* sDRW = smem + L.DRW; float* sDF = smem + L.DF;
     float* sDB = smem + L.DB;   float* sDSIM = smem + L.DSIM; float* sSIMr = smem + L.SIMr; float* sDRWp = smem + L.DRWp;
     float* sGZ = smem + L.GZ;   float* sDR = smem + L.DR;   float* sDKR = smem + L.DKR; float* sDKW = smem + L.DKW;
     float* sDE = smem + L.DE;   float* sDV = smem + L.DV;   float* sDHC = smem + L.DHC; float* sgC = smem + L.gC;
@@ -92,11 +92,14 @@ __global__ __launch_bounds__(DT) void dnc_seq_bwd_kernel(DncBwdArgs a, DncBwdLds
     const int nslZ = max(1, DT / kg4), nperZ = (4 * hid + nslZ - 1) / nslZ;
     const int nslH = max(1, DT / hg4), nperH = (IP + nslH - 1) / nslH;
 
-    // carried gradients start at zero (the loss depends on the outputs only)
-    for (int i = tid0; i < N; i += DT) { sgP[i] = 0.f; sgU[i] = 0.f; }
-    for (int i = tid0; i < RN; i += DT) sgRW[i] = 0.f;
-    for (int i = tid0; i < a.ldkT; i += DT) sGZ[i] = 0.f;
-    for (int i = tid0; i < hid; i += DT) sgC[i] = 0.f;
+    // carried gradients start at zero (the loss depends on the outputs only) or, for a segment of a longer
+    // sequence, at the values the following segment left behind
+    float* cy = a.gcarry ? a.gcarry + (size_t)b * (2 * N + RN + a.ldkT + hid) : nullptr;
+    const bool cin = cy && a.carry_in;
+    for (int i = tid0; i < N; i += DT) { sgP[i] = cin ? cy[i] : 0.f; sgU[i] = cin ? cy[N + i] : 0.f; }
+    for (int i = tid0; i < RN; i += DT) sgRW[i] = cin ? cy[2 * N + i] : 0.f;
+    for (int i = tid0; i < a.ldkT; i += DT) sGZ[i] = (cin && i < K) ? cy[2 * N + RN + i] : 0.f;
+    for (int i = tid0; i < hid; i += DT) sgC[i] = cin ? cy[2 * N + RN + a.ldkT + i] : 0.f;
     __syncthreads();
 
     for (int t = S - 1; t >= 0; --t) {
@@ -109,6 +112,10 @@ __global__ __launch_bounds__(DT) void dnc_seq_bwd_kernel(DncBwdArgs a, DncBwdLds
         const float* Mp = (t > 0) ? a.rec_M + (bt - 1) * N * W : a.mem0 + (size_t)b * N * W;
         const float* Lt = a.rec_L + bt * N * N;
         const float* Lp = (t > 0) ? a.rec_L + (bt - 1) * N * N : a.link0 + (size_t)b * N * N;
+        // single-use records are read where they are consumed (L2 hits), not staged: keeps config 5 inside 160 KiB
+        const float* gRW = a.rec_rw + bt * RN;
+        const float* gFV = a.rec_fwd + bt * RN;
+        const float* gBV = a.rec_bwd + bt * RN;
 
         // ------------------------------------------------------------ load this step's records
         for (int c = tid; c < IP; c += DT) { sI[c] = a.rec_ifc[bt * IP + c]; sDX[c] = 0.f; }
@@ -123,10 +130,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_bwd_kernel(DncBwdArgs a, DncBwdLds
             sDWW[n] = 0.f; sDPp[n] = 0.f;
         }
         for (int i = tid; i < RN; i += DT) {
-            sRW[i] = a.rec_rw[bt * RN + i];
             sCR[i] = a.rec_cr[bt * RN + i];
-            sFV[i] = a.rec_fwd[bt * RN + i];
-            sBV[i] = a.rec_bwd[bt * RN + i];
             sRWp[i] = (t > 0) ? a.rec_rw[(bt - 1) * RN + i] : a.rw0[(size_t)b * RN + i];
             sDRWp[i] = 0.f;
         }
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_bwd_kernel(DncBwdArgs a, DncBwdLds
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, s1 = 0.f;
             for (int n = lane; n < N; n += 64) {
                 const float g = sDRW[i * N + n];
-                p0 += g * sBV[i * N + n]; p1 += g * sFV[i * N + n]; p2 += g * sCR[i * N + n];
+                p0 += g * gBV[i * N + n]; p1 += g * gFV[i * N + n]; p2 += g * sCR[i * N + n];
                 s1 += sCR[i * N + n] * (rm[2] * g);
             }
             p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2); s1 = wave_sum(s1);
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_bwd_kernel(DncBwdArgs a, DncBwdLds
                             if (gl == 0) accNk[i] += dD * nm;
                             const float* kp = sI + d.oKr + i * W + gl * 4;
                             const float* dr = sDR + i * W + gl * 4;
-                            const float rwn = sRW[i * N + n];
+                            const float rwn = gRW[i * N + n];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) g[e] += rwn * dr[e] + ddot * kp[e];
                             accK[i] += ddot * m;
@@ -552,6 +556,12 @@ __global__ __launch_bounds__(DT) void dnc_seq_bwd_kernel(DncBwdArgs a, DncBwdLds
         }
         __syncthreads();
     }
+    if (cy) {
+        for (int i = tid0; i < N; i += DT) { cy[i] = sgP[i]; cy[N + i] = sgU[i]; }
+        for (int i = tid0; i < RN; i += DT) cy[2 * N + i] = sgRW[i];
+        for (int i = tid0; i < a.ldkT; i += DT) cy[2 * N + RN + i] = sGZ[i];
+        for (int i = tid0; i < hid; i += DT) cy[2 * N + RN + a.ldkT + i] = sgC[i];
+    }
 }
 
 extern "C" int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value,
@@ -563,7 +573,7 @@ extern "C" int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hi
                                const float* rec_al, const float* rec_p, const float* rec_fwd, const float* rec_bwd,
                                const float* rec_M, const float* rec_L, const float* rec_ypre,
                                const float* dout, float* gM, float* gL, float* dgates, float* dxi, float* dypre,
-                               void* stream) {
+                               float* gcarry, int carry_in, void* stream) {
     DncBwdArgs a;
     dnc_fill_dims(a.d, B, S, N, W, R, Wn, hid, O, clip_value);
     NTK_REQUIRE(B > 0 && S > 0, NTK_ERR_BAD_SHAPE, "ntk_dnc_seq_bwd: B=%d S=%d", B, S);
@@ -587,7 +597,7 @@ extern "C" int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hi
     a.rec_gates = rec_gates; a.rec_c = rec_c; a.rec_ifc = rec_ifc; a.rec_u = rec_u; a.rec_ww = rec_ww; a.rec_rw = rec_rw;
     a.rec_cw = rec_cw; a.rec_cr = rec_cr; a.rec_al = rec_al; a.rec_p = rec_p; a.rec_fwd = rec_fwd; a.rec_bwd = rec_bwd;
     a.rec_M = rec_M; a.rec_L = rec_L; a.rec_ypre = rec_ypre; a.dout = dout; a.gM = gM; a.gL = gL;
-    a.dgates = dgates; a.dxi = dxi; a.dypre = dypre;
+    a.dgates = dgates; a.dxi = dxi; a.dypre = dypre; a.gcarry = gcarry; a.carry_in = carry_in;
     DncBwdLds L;
     dnc_bwd_lds(a.d, ldkT, ldhT, L);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);

@@ -192,37 +192,106 @@ class DNC(object):
                 "u": e(N), "ww": e(Wn, N), "rw": e(R, N), "cw": e(Wn, N), "cr": e(R, N), "al": e(Wn, N), "p": e(Wn, N),
                 "fwd": e(R, Wn, N), "bwd": e(R, Wn, N), "M": e(N, W), "L": e(Wn, N, N), "ypre": e(self.O)}
 
-    def run_projected(self, xproj, B, S, prev_state=None, record=False):
-        """Sequence kernel on an already projected input (xproj [B*S, 4*hid] = X WxT^T)."""
-        dev = self.device
-        st = prev_state or self.initial_state(B)
+    #: per-sequence-step record budget above which a recorded pass switches to segmented BPTT (bytes).  Config 5
+    #: (N=512: 1 MiB of link per step and sequence, 3250 steps) cannot keep every step: the forward pass then keeps
+    #: one state checkpoint per segment and backward_sequence re-records segment by segment, last to first.
+    record_budget_bytes = 24 << 30
+    #: steps per BPTT segment; None = derive from record_budget_bytes (whole sequence when it fits)
+    bptt_segment = None
+    last_record = None
+    last_segments = None
+    last_initial = None
+
+    def _record_floats_per_step(self):
+        N, W, R, Wn, hid = self.N, self.W, self.R, self.Wn, self.hid
+        return (self.ldz + 5 * hid + self.ldh + self.ldy + self.IP + N + 4 * Wn * N + 2 * R * N + 2 * R * Wn * N +
+                N * W + Wn * N * N + self.O)
+
+    def _segment_len(self, B, S):
+        if self.bptt_segment is not None:
+            return max(1, min(S, int(self.bptt_segment)))
+        per_step = 4 * B * self._record_floats_per_step()
+        return max(1, min(S, self.record_budget_bytes // per_step))
+
+    def _launch_fwd(self, xproj, B, S, st, rec):
+        """One ntk_dnc_seq_fwd launch over contiguous xproj [B*S, 4*hid] starting from state `st` (not modified)."""
         acc = st.access_state
         # the kernel updates the state in place: work on private copies
         mem, link = acc.memory.clone().contiguous(), acc.linkage.link.clone().contiguous()
         usage, rw, ww = acc.usage.clone().contiguous(), acc.read_weights.clone().contiguous(), acc.write_weights.clone().contiguous()
         prec, reads = acc.linkage.precedence_weights.clone().contiguous(), st.access_output.clone().contiguous()
         hc = torch.cat([st.controller_state.hidden, st.controller_state.cell], dim=1).contiguous()
-        out = torch.empty((B, S, self.O), device=dev)
-        rec = self._alloc_records(B, S) if record else {}
-        recp = [(_P(rec[k]) if record else None) for k in self.REC_NAMES]
+        out = torch.empty((B, S, self.O), device=self.device)
+        recp = [(_P(rec[k]) if rec else None) for k in self.REC_NAMES]
         _lib.check(_lib.lib().ntk_dnc_seq_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value,
                                               _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
                                               _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), *recp, _lib.stream()),
                    "ntk_dnc_seq_fwd")
-        self.last_record = rec
-        self.last_initial = st
         new = DNCState(reads, AccessState(mem, rw, ww, TemporalLinkageState(link, prec), usage),
                        LSTMState(hc[:, :self.hid].contiguous(), hc[:, self.hid:].contiguous()))
-        return out.transpose(0, 1), new          # time-major [S,B,O]
+        return out, new
+
+    def run_projected(self, xproj, B, S, prev_state=None, record=False):
+        """Sequence kernel on an already projected input (xproj [B*S, 4*hid] = X WxT^T)."""
+        st = prev_state or self.initial_state(B)
+        seg = self._segment_len(B, S) if record else S
+        self.last_initial = st
+        self.last_segments = None
+        if seg >= S:
+            rec = self._alloc_records(B, S) if record else {}
+            out, new = self._launch_fwd(xproj, B, S, st, rec)
+            self.last_record = rec
+            return out.transpose(0, 1), new          # time-major [S,B,O]
+        # segmented: forward without records, one state checkpoint per segment
+        xp = xproj.view(B, S, 4 * self.hid)
+        out = torch.empty((B, S, self.O), device=self.device)
+        ckpt, bounds = [], []
+        for s0 in range(0, S, seg):
+            s1 = min(S, s0 + seg)
+            ckpt.append(st)
+            bounds.append((s0, s1))
+            o, st = self._launch_fwd(xp[:, s0:s1].contiguous().view(B * (s1 - s0), 4 * self.hid), B, s1 - s0, st, {})
+            out[:, s0:s1] = o
+        self.last_record = {}
+        self.last_segments = (xp, ckpt, bounds)
+        return out.transpose(0, 1), st
+
+    def _launch_bwd(self, B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, gcarry, carry_in):
+        dev, hid = self.device, self.hid
+        acc = st0.access_state
+        hc0 = torch.cat([st0.controller_state.hidden, st0.controller_state.cell], dim=1).contiguous()
+        dgates = torch.empty((B, S, 4 * hid), device=dev)
+        dxi = torch.empty((B, S, self.IP), device=dev)
+        dypre = torch.empty((B, S, self.OP), device=dev)
+        c = lambda t: _P(t.contiguous())
+        _lib.check(_lib.lib().ntk_dnc_seq_bwd(
+            B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value,
+            _P(WrT), ldkT, _P(WiT), ldhT, _P(self.Wy),
+            c(acc.memory), c(acc.linkage.link), c(acc.usage), c(acc.read_weights), c(acc.write_weights),
+            c(acc.linkage.precedence_weights), _P(hc0),
+            _P(rec["gates"]), _P(rec["c"]), _P(rec["ifc"]), _P(rec["u"]), _P(rec["ww"]), _P(rec["rw"]), _P(rec["cw"]),
+            _P(rec["cr"]), _P(rec["al"]), _P(rec["p"]), _P(rec["fwd"]), _P(rec["bwd"]), _P(rec["M"]), _P(rec["L"]),
+            _P(rec["ypre"]), _P(dout), _P(gM), _P(gL), _P(dgates), _P(dxi), _P(dypre),
+            _P(gcarry) if gcarry is not None else None, 1 if carry_in else 0, _lib.stream()), "ntk_dnc_seq_bwd")
+        return dgates, dxi, dypre
+
+    def _weight_grads(self, X2, rec, dgates, dxi, dypre, BS, accumulate):
+        P, hid = self.params, self.hid
+        gemm_tn(dgates.view(BS, 4 * hid), X2, P.view("WxT", grad=True), accumulate=accumulate)
+        gemm_tn(rec["z"].view(BS, self.ldz), dgates.view(BS, 4 * hid), P.view("Wr", grad=True), accumulate=accumulate)
+        gemm_tn(rec["hc"].view(BS, self.ldh), dxi.view(BS, self.IP), P.view("Wi", grad=True), accumulate=accumulate)
+        gemm_tn(rec["yin"].view(BS, self.ldy), dypre.view(BS, self.OP), P.view("Wy", grad=True), accumulate=accumulate)
 
     def backward_sequence(self, X, dout):
         """BPTT through the last recorded sequence (run_projected(..., record=True)).
         X [B,S,ldx] serialised inputs, dout [B,S,O] = d loss / d output.  Returns the gradients in the
-        reference's Sonnet variable layout ({name: tensor on device})."""
+        reference's Sonnet variable layout ({name: tensor on device}).  When the forward pass was segmented
+        (see record_budget_bytes) each segment is re-recorded from its checkpoint, last segment first; the
+        state gradients flow between segments through gM / gL / gcarry."""
         if self.Wn != 1:
             raise _lib.NtkError("DNC BPTT on the HIP path implements num_writes == 1 (got %d)" % self.Wn)
         rec, st0 = self.last_record, self.last_initial
-        if not rec:
+        if not rec and not self.last_segments:
             raise _lib.NtkError("backward_sequence needs a recorded forward pass (record=True)")
         B, S, _ = X.shape
         dev, L, stream = self.device, _lib.lib(), _lib.stream()
@@ -232,28 +301,25 @@ class DNC(object):
         WiT = torch.empty((self.IP, ldhT), device=dev)
         _lib.check(L.ntk_transpose_pad(_P(self.Wr), 4 * hid, _P(WrT), ldkT, self.K, 4 * hid, stream), "ntk_transpose_pad")
         _lib.check(L.ntk_transpose_pad(_P(self.Wi), self.IP, _P(WiT), ldhT, hid, self.IP, stream), "ntk_transpose_pad")
-        acc = st0.access_state
-        hc0 = torch.cat([st0.controller_state.hidden, st0.controller_state.cell], dim=1).contiguous()
         gM = torch.zeros((B, self.N, self.W), device=dev)
         gL = torch.zeros((B, self.N, self.N), device=dev)
-        dgates = torch.empty((B, S, 4 * hid), device=dev)
-        dxi = torch.empty((B, S, self.IP), device=dev)
-        dypre = torch.empty((B, S, self.OP), device=dev)
-        c = lambda t: _P(t.contiguous())
-        _lib.check(L.ntk_dnc_seq_bwd(
-            B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value,
-            _P(WrT), ldkT, _P(WiT), ldhT, _P(self.Wy),
-            c(acc.memory), c(acc.linkage.link), c(acc.usage), c(acc.read_weights), c(acc.write_weights),
-            c(acc.linkage.precedence_weights), _P(hc0),
-            _P(rec["gates"]), _P(rec["c"]), _P(rec["ifc"]), _P(rec["u"]), _P(rec["ww"]), _P(rec["rw"]), _P(rec["cw"]),
-            _P(rec["cr"]), _P(rec["al"]), _P(rec["p"]), _P(rec["fwd"]), _P(rec["bwd"]), _P(rec["M"]), _P(rec["L"]),
-            _P(rec["ypre"]), c(dout), _P(gM), _P(gL), _P(dgates), _P(dxi), _P(dypre), stream), "ntk_dnc_seq_bwd")
-        BS = B * S
-        P = self.params
-        gemm_tn(dgates.view(BS, 4 * hid), X.view(BS, self.ldx), P.view("WxT", grad=True))
-        gemm_tn(rec["z"].view(BS, self.ldz), dgates.view(BS, 4 * hid), P.view("Wr", grad=True))
-        gemm_tn(rec["hc"].view(BS, self.ldh), dxi.view(BS, self.IP), P.view("Wi", grad=True))
-        gemm_tn(rec["yin"].view(BS, self.ldy), dypre.view(BS, self.OP), P.view("Wy", grad=True))
+        dout = dout.contiguous()
+        if not self.last_segments:
+            dgates, dxi, dypre = self._launch_bwd(B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, None, False)
+            self._weight_grads(X.view(B * S, self.ldx), rec, dgates, dxi, dypre, B * S, False)
+            return self._unpack(grad=True)
+        xp, ckpt, bounds = self.last_segments
+        gcarry = torch.zeros((B, 2 * self.N + self.R * self.N + ldkT + hid), device=dev)
+        first = True
+        for st, (s0, s1) in zip(reversed(ckpt), reversed(bounds)):
+            n = s1 - s0
+            rec = self._alloc_records(B, n)
+            self._launch_fwd(xp[:, s0:s1].contiguous().view(B * n, 4 * hid), B, n, st, rec)
+            dgates, dxi, dypre = self._launch_bwd(B, n, st, rec, dout[:, s0:s1].contiguous(), WrT, ldkT, WiT, ldhT, gM, gL,
+                                                  gcarry, not first)
+            self._weight_grads(X[:, s0:s1].contiguous().view(B * n, self.ldx), rec, dgates, dxi, dypre, B * n, not first)
+            first = False
+            del rec
         return self._unpack(grad=True)
 
     def __call__(self, inputs, prev_state):

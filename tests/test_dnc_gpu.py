@@ -146,6 +146,7 @@ BWD_CASES = [
     ("small_zero_state", 12, 2, 32, 12, 3, 24, 20.0, 6, 2, True),
     ("tight_clip", 10, 2, 16, 8, 2, 16, 0.4, 4, 2, False),
     ("c3_shape", 514, 2, 256, 64, 4, 200, 20.0, 4, 1, False),
+    ("c5_shape", 514, 2, 512, 128, 4, 200, 20.0, 3, 1, False),
 ]
 
 
@@ -200,6 +201,36 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, h
         worst[k] = float(np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) + 1e-30))
     bad = {k: v for k, v in worst.items() if v > 3e-3}
     assert not bad, bad
+
+
+def test_dnc_segmented_bptt_equals_whole_sequence(cuda):
+    """Long-horizon path (config 5): BPTT in re-recorded segments from state checkpoints gives the gradients of the
+    single recorded pass (same kernels, same order inside a step; only the LDS-atomic column sums may reorder)."""
+    from ntmtrack import dnc as G
+    rng = np.random.default_rng(23)
+    N, W, R, hid, O, Din, S, B = 32, 12, 3, 24, 2, 20, 13, 3
+    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=1, hidden_size=hid, clip_value=20.0)
+    p = D.init_params(cfg, rng)
+    for k in p:
+        if k.startswith("memory_access/") and k.endswith("/w"):
+            p[k] = (p[k] * 4).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((S, B, Din)).astype(np.float32)).to(cuda)
+    dout = torch.from_numpy(rng.standard_normal((B, S, O)).astype(np.float32)).to(cuda)
+    res = {}
+    for seg in (None, 5, 1):
+        core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, 20.0, device=cuda)
+        core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+        core.bptt_segment = seg
+        out, st = core.run_sequence(x, None, record=True)
+        assert (core.last_segments is not None) == (seg is not None)
+        grads = core.backward_sequence(core.last_X, dout)
+        res[seg] = (out.cpu().numpy(), st.access_state.memory.cpu().numpy(), {k: v.cpu().numpy() for k, v in grads.items()})
+    for seg in (5, 1):
+        np.testing.assert_array_equal(res[seg][0], res[None][0])
+        np.testing.assert_array_equal(res[seg][1], res[None][1])
+        for k, g in res[None][2].items():
+            scale = np.max(np.abs(g)) + 1e-30
+            assert np.max(np.abs(res[seg][2][k] - g)) <= 2e-5 * scale, (seg, k)
 
 
 def test_dnc_offset_tracker_training_step(cuda):
