@@ -237,9 +237,9 @@ def main():
             "config": {"workload": ("BASELINE configs[1]: VGG-16 conv1_1..conv4_3 + NTMCell(128x20, hidden 200, R4/W1) "
                                     "direct_offset_output %s step, batch %d sequences/GPU, seq_len %d, 224x224 frames"
                                     % ("training" if args.mode == "train" else "inference", B, T)) if args.model == "ntm" else
-                                   ("BASELINE configs[2]: VGG-16 conv1_1..conv4_3 + DNC core (mem %dx%d, 4 read heads, hidden 200, clip 20) "
+                                   ("BASELINE configs[%d]: VGG-16 conv1_1..conv4_3 + DNC core (mem %dx%d, 4 read heads, hidden 200, clip 20) "
                                     "direct_offset_output_with_dnc %s step, batch %d sequences/GPU, seq_len %d"
-                                    % (trk.core.N, trk.core.W, "training" if args.mode == "train" else "inference", B, T)),
+                                    % (4 if trk.core.N >= 512 else 2, trk.core.N, trk.core.W, "training" if args.mode == "train" else "inference", B, T)),
                        "global_batch": world * B, "seq_len": T, "steps_per_sequence": T * 65,
                        "parallelism": "dp%d" % world, "mode": args.mode},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_relu_kernel (VGG trunk, 10 layers)" if args.conv_dtype == "f32"

@@ -96,3 +96,32 @@ def test_config4_shape_training_step_properties(cuda):
     gh, gf = half.cell.params.grad, full.cell.params.grad
     rel = float((gf - 2 * gh).abs().max() / gf.abs().max())
     assert rel < 1e-4, rel
+
+
+def test_config5_shape_dnc_training_step_properties(cuda):
+    """BASELINE config 5's cell (DNC 512x128, 4 read heads) at a reduced batch and length, through the SEGMENTED
+    BPTT that its full length (3250 steps) requires: finite, the duplicated batch doubles loss and gradient, and
+    one optimiser step on the same batch lowers the loss."""
+    from ntmtrack import tracker
+    B, T = 4, 3
+    g = torch.Generator().manual_seed(10)
+    fmap_h = torch.relu(torch.randn((B // 2 * T, 28, 28, 512), generator=g)).to(cuda)
+    gts_h = torch.rand((B // 2, 64), generator=g).to(cuda)
+    offs_h = (torch.rand((B // 2, T, 2), generator=g) - 0.5).to(cuda)
+    kw = dict(vgg_weights=None, mem_size=512, mem_dim=128, device=cuda, seed=6, learning_rate=1e-3)
+    half = tracker.DNCOffsetTracker(B // 2, T, **kw)
+    half.core.bptt_segment = 65
+    loss_h, _ = half.loss_and_grads(fmap_h, gts_h, offs_h)
+    full = tracker.DNCOffsetTracker(B, T, **kw)
+    full.core.bptt_segment = 50                  # segment boundaries need not align with frames
+    args = (torch.cat([fmap_h, fmap_h]), torch.cat([gts_h, gts_h]), torch.cat([offs_h, offs_h]))
+    loss_f, _ = full.loss_and_grads(*args)
+    torch.cuda.synchronize()
+    assert full.core.last_segments is not None and len(full.core.last_segments[1]) == 4
+    gh, gf = half.core.params.grad, full.core.params.grad
+    assert torch.isfinite(gf).all()
+    np.testing.assert_allclose(float(loss_f.cpu()), 2 * float(loss_h.cpu()), rtol=1e-5)
+    assert float((gf - 2 * gh).abs().max() / gf.abs().max()) < 1e-4
+    full.opt.step()
+    loss_2, _ = full.loss_and_grads(*args)
+    assert float(loss_2.cpu()) < float(loss_f.cpu())
