@@ -71,6 +71,11 @@ int ntk_vgg_conv3x3_relu_bf16(const void* in_bf16, const void* w_packed_bf16, co
 int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, const float* bias, void* out_bf16,
                                      int frames, int H, int W, int cin, int cout, void* stream);
 
+/* slim.max_pool2d [2,2] stride 2 on NHWC fp32 (vgg.py:155-161) as its own launch (ntk_maxpool2x2).
+ * The trunk fuses the pool into the epilogue of conv1_2 / conv2_2 / conv3_3 (fuse_pool); this entry point is the
+ * un-fused form with identical results.  H, W even; C a multiple of 4. */
+int ntk_maxpool2x2(const float* in, float* out, int frames, int H, int W, int C, void* stream);
+
 /* Tuning knob: 0 two LDS buffers / 2 workgroups per CU, 1 = 0 + static wave
  * priority, 2 one LDS buffer / 3 workgroups per CU, 3 = 2 at 4 workgroups per
  * CU (spills), 4 (default) LDS-DMA staging, swizzled un-padded LDS image, 4
@@ -148,6 +153,33 @@ int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int hid, int shi
                     float* dgates, float* du, float* dM0, float* dw0, float* dread0, float* dcs0,
                     void* stream);
 
+/* One step of the cell (ntk_ntm_step_fwd/bwd) = the sequence kernels with S = 1; argument meaning as
+ * ntk_ntm_seq_fwd / ntk_ntm_seq_bwd (the state AFTER the step takes the place of the final state). */
+int ntk_ntm_step_fwd(int B, int N, int Md, int R, int Wh, int hid, int shift_range, int O, int write_first,
+                     const float* xproj, const float* Wr, const float* Wa,
+                     const float* M_prev, const float* w_prev, const float* read_prev, const float* cs_prev,
+                     float* logits, float* outputs, float* M, float* w, float* read, float* cs,
+                     float* st_z, float* st_gates, float* st_c, float* st_h, float* st_u,
+                     float* st_wc, float* st_wv, float* st_w, float* st_M, float* st_read, void* stream);
+int ntk_ntm_step_bwd(int B, int N, int Md, int R, int Wh, int hid, int shift_range, int O, int write_first,
+                     const float* WrT, int ldkT, const float* WaT, int ldhT,
+                     const float* M_prev, const float* w_prev, const float* cs_prev,
+                     const float* st_gates, const float* st_c, const float* st_u,
+                     const float* st_wc, const float* st_wv, const float* st_w, const float* st_M,
+                     const float* dlogits,
+                     const float* dM, const float* dw, const float* dread, const float* dcs,
+                     float* dgates, float* du, float* dM_prev, float* dw_prev, float* dread_prev, float* dcs_prev,
+                     void* stream);
+
+/* tf.contrib.rnn.BasicLSTMCell pointwise step (ntm_cell.py:45-50; gate pre-activations pre [B,4*hid] = [x,h] W + b from
+ * ntk_gemm_nt_f32, TF block order i | j | f | o): c = c_prev*sigmoid(f + forget_bias) + sigmoid(i)*tanh(j),
+ * h = tanh(c)*sigmoid(o); act [B,4*hid] (nullable) keeps the activated gates for the backward, which returns the
+ * gradient of the pre-activations and of c_prev (dh or dc may be null = zero). */
+int ntk_lstm_step_fwd(const float* pre, const float* c_prev, float forget_bias, float* c, float* h, float* act,
+                      int B, int hid, void* stream);
+int ntk_lstm_step_bwd(const float* act, const float* c_prev, const float* c, const float* dh, const float* dc,
+                      float* dpre, float* dc_prev, int B, int hid, void* stream);
+
 /* trainable initial state (ntm_cell.py:284-315): out[b][i] = act(v[i]),
  * act 0 = tanh, 1 = sigmoid; and its gradient summed over the batch */
 int ntk_ntm_init_state(const float* v, float* out, int n, int B, int act, void* stream);
@@ -191,6 +223,30 @@ int ntk_dnc_freeness(const float* write_weights, const float* free_gate, const f
                      const float* prev_usage, float* usage, int B, int N, int Wn, int R, void* stream);
 int ntk_dnc_write_allocation_weights(const float* usage, const float* write_gates, float* out, int B, int N, int Wn,
                                      void* stream);
+
+/* MemoryAccess pieces (dnc/access.py): the activations of _read_inputs (:160-218) on the RAW outputs of the ten
+ * interface linears in the packed order [write_vectors | erase_vectors | free_gate | allocation_gate | write_gate |
+ * read_mode | write_keys | write_strengths | read_keys | read_strengths] (row stride ldr); `act` receives each field
+ * as a contiguous [B,width] array at act + B*offset(field).  _write_weights (:220-257), _erase_and_write (:32-63),
+ * _read_weights (:259-303), read words (:151), and the whole step MemoryAccess._build (:113-158) = SURVEY's
+ * ntk_dnc_access_step_fwd.  The step's backward is part of ntk_dnc_seq_bwd (no stand-alone form).
+ * Workspaces (floats): write_weights 2*B*Wn*N + B*Wn; read_weights B*R*N*(1+2*Wn). */
+int ntk_dnc_interface_activations(const float* raw, int ldr, float* act, int B, int N, int W, int R, int Wn, void* stream);
+int ntk_dnc_write_weights(const float* memory, const float* usage, const float* write_keys, const float* write_strengths,
+                          const float* allocation_gate, const float* write_gate, float* write_weights, float* workspace,
+                          int B, int N, int W, int Wn, void* stream);
+int ntk_dnc_erase_and_write(const float* memory, const float* address, const float* reset_weights, const float* values,
+                            float* out, int B, int N, int W, int Wn, void* stream);
+int ntk_dnc_read_weights(const float* memory, const float* prev_read_weights, const float* link, const float* read_keys,
+                         const float* read_strengths, const float* read_mode, float* read_weights, float* workspace,
+                         int B, int N, int W, int R, int Wn, void* stream);
+int ntk_dnc_read_words(const float* read_weights, const float* memory, float* out, int B, int N, int W, int R, void* stream);
+size_t ntk_dnc_access_step_workspace_bytes(int B, int N, int W, int R, int Wn);
+int ntk_dnc_access_step_fwd(const float* iface_raw, int ldr, const float* memory, const float* read_weights,
+                            const float* write_weights, const float* link, const float* precedence, const float* usage,
+                            float* memory_out, float* read_weights_out, float* write_weights_out, float* link_out,
+                            float* precedence_out, float* usage_out, float* read_words, float* workspace,
+                            int B, int N, int W, int R, int Wn, void* stream);
 
 /* Full BPTT through a recorded DNC sequence (num_writes == 1).  WrT [4*hid][ldkT], WiT [IP][ldhT]
  * are transposed copies of Wr / Wi; *0 pointers are the state BEFORE step 0; gM [B,N,W] and
@@ -242,6 +298,11 @@ int ntk_resize_bilinear(const float* image, int H, int W, int C, float* out, int
  * pred [B,T-1,O] (nullable), loss [1], dlogits [B,S,O] (nullable). */
 int ntk_offset_loss(const float* logits, const float* offsets, float* pred, float* loss,
                     float* dlogits, int B, int T, int NF, int O, void* stream);
+
+/* the same in two calls (ntk_offset_loss_fwd/bwd) */
+int ntk_offset_loss_fwd(const float* logits, const float* offsets, float* pred, float* loss, int B, int T, int NF, int O,
+                        void* stream);
+int ntk_offset_loss_bwd(const float* logits, const float* offsets, float* dlogits, int B, int T, int NF, int O, void* stream);
 
 /* copy-task head (main.py:1603-1610, BASELINE configs[0]): loss = tf.losses.log_loss(labels,
  * sigmoid(logits)) (mean over all n elements, epsilon 1e-7) and d loss / d logits (nullable). */

@@ -46,6 +46,20 @@ def _sig(lib):
         "ntk_dnc_directional_read_weights": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
         "ntk_dnc_freeness": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_dnc_write_allocation_weights": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+        "ntk_dnc_interface_activations": (c_int, [P, c_int, P] + [c_int] * 5 + [P]),
+        "ntk_dnc_write_weights": (c_int, [P] * 8 + [c_int] * 4 + [P]),
+        "ntk_dnc_erase_and_write": (c_int, [P] * 5 + [c_int] * 4 + [P]),
+        "ntk_dnc_read_weights": (c_int, [P] * 8 + [c_int] * 5 + [P]),
+        "ntk_dnc_read_words": (c_int, [P] * 3 + [c_int] * 4 + [P]),
+        "ntk_dnc_access_step_workspace_bytes": (ctypes.c_size_t, [c_int] * 5),
+        "ntk_dnc_access_step_fwd": (c_int, [P, c_int] + [P] * 14 + [c_int] * 5 + [P]),
+        "ntk_ntm_step_fwd": (c_int, [c_int] * 9 + [P] * 24),
+        "ntk_ntm_step_bwd": (c_int, [c_int] * 9 + [P, c_int, P, c_int] + [P] * 22),
+        "ntk_lstm_step_fwd": (c_int, [P, P, ctypes.c_float, P, P, P, c_int, c_int, P]),
+        "ntk_lstm_step_bwd": (c_int, [P] * 7 + [c_int, c_int, P]),
+        "ntk_maxpool2x2": (c_int, [P, P] + [c_int] * 4 + [P]),
+        "ntk_offset_loss_fwd": (c_int, [P] * 4 + [c_int] * 4 + [P]),
+        "ntk_offset_loss_bwd": (c_int, [P] * 3 + [c_int] * 4 + [P]),
         "ntk_dnc_seq_bwd": (c_int, [c_int] * 8 + [ctypes.c_float] + [P, c_int, P, c_int, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P, c_int, P]),
         "ntk_gather_serialize": (c_int, [P, P, P] + [c_int] * 9 + [P]),
         "ntk_gather_serialize_online": (c_int, [P, P, P] + [c_int] * 9 + [P]),

@@ -121,6 +121,97 @@ __global__ __launch_bounds__(1024) void allocation_kernel(const float* __restric
     }
 }
 
+
+// MemoryAccess._read_inputs activations (access.py:160-218) on the raw outputs of the ten linears laid out in the
+// packed interface order (DncDims); fields are written de-interleaved, each as a contiguous [B, width] array at
+// act + B * offset(field), so the module kernels take plain pointers.
+__global__ void interface_act_kernel(const float* __restrict__ raw, int ldr, float* __restrict__ act, DncDims d) {
+    const int b = blockIdx.x, B = gridDim.x;
+    const float* x = raw + (size_t)b * ldr;
+    const int M = 1 + 2 * d.Wn;
+    for (int c = threadIdx.x; c < d.I; c += blockDim.x) {
+        float v = x[c];
+        int off, width;
+        if (c < d.oE) { off = d.oV; width = d.oE - d.oV; }
+        else if (c < d.oF) { off = d.oE; width = d.oF - d.oE; v = dnc_sigmoid(v); }
+        else if (c < d.oAg) { off = d.oF; width = d.oAg - d.oF; v = dnc_sigmoid(v); }
+        else if (c < d.oWg) { off = d.oAg; width = d.oWg - d.oAg; v = dnc_sigmoid(v); }
+        else if (c < d.oRm) { off = d.oWg; width = d.oRm - d.oWg; v = dnc_sigmoid(v); }
+        else if (c < d.oKw) {
+            off = d.oRm; width = d.oKw - d.oRm;
+            const int i = (c - d.oRm) / M;
+            const float* r = x + d.oRm + i * M;
+            float mx = r[0];
+            for (int m = 1; m < M; ++m) mx = fmaxf(mx, r[m]);
+            float sum = 0.f;
+            for (int m = 0; m < M; ++m) sum += expf(r[m] - mx);
+            v = expf(v - mx) / sum;
+        }
+        else if (c < d.oBw) { off = d.oKw; width = d.oBw - d.oKw; }
+        else if (c < d.oKr) { off = d.oBw; width = d.oKr - d.oBw; }
+        else if (c < d.oBr) { off = d.oKr; width = d.oBr - d.oKr; }
+        else { off = d.oBr; width = d.I - d.oBr; }
+        act[(size_t)B * off + (size_t)b * width + (c - off)] = v;
+    }
+}
+
+// _write_weights mix (access.py:247-257): ww = write_gate * (alloc_gate * allocation + (1 - alloc_gate) * content);
+// also the gate product handed to write_allocation_weights (:238-241)
+__global__ void gate_product_kernel(const float* __restrict__ ag, const float* __restrict__ wg, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ag[i] * wg[i];
+}
+__global__ void write_mix_kernel(const float* __restrict__ alloc, const float* __restrict__ content, const float* __restrict__ ag,
+                                 const float* __restrict__ wg, float* __restrict__ out, int N) {
+    const int bj = blockIdx.x;
+    const float a = ag[bj], g = wg[bj];
+    for (int n = threadIdx.x; n < N; n += blockDim.x)
+        out[(size_t)bj * N + n] = g * (a * alloc[(size_t)bj * N + n] + (1.0f - a) * content[(size_t)bj * N + n]);
+}
+
+// _erase_and_write (access.py:32-63): M' = M * prod_j (1 - ww_j (x) e_j) + sum_j ww_j (x) v_j
+__global__ void erase_write_kernel(const float* __restrict__ mem, const float* __restrict__ ww, const float* __restrict__ er,
+                                   const float* __restrict__ val, float* __restrict__ out, int N, int W, int Wn) {
+    const int b = blockIdx.x;
+    for (int idx = threadIdx.x; idx < N * W; idx += blockDim.x) {
+        const int n = idx / W, w = idx - n * W;
+        float keep = 1.f, add = 0.f;
+        for (int j = 0; j < Wn; ++j) {
+            const float a = ww[((size_t)b * Wn + j) * N + n];
+            keep *= (1.0f - a * er[((size_t)b * Wn + j) * W + w]);
+            add += a * val[((size_t)b * Wn + j) * W + w];
+        }
+        out[(size_t)b * N * W + idx] = mem[(size_t)b * N * W + idx] * keep + add;
+    }
+}
+
+// _read_weights mix (access.py:283-303): read_mode [B,R,1+2Wn] = [backward x Wn | forward x Wn | content]
+__global__ void read_mix_kernel(const float* __restrict__ content, const float* __restrict__ fwd, const float* __restrict__ bwd,
+                                const float* __restrict__ mode, float* __restrict__ out, int N, int Wn) {
+    const int bi = blockIdx.x;
+    const float* m = mode + (size_t)bi * (1 + 2 * Wn);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float v = m[2 * Wn] * content[(size_t)bi * N + n];
+        float f = 0.f, bsum = 0.f;
+        for (int j = 0; j < Wn; ++j) {
+            f += m[Wn + j] * fwd[((size_t)bi * Wn + j) * N + n];
+            bsum += m[j] * bwd[((size_t)bi * Wn + j) * N + n];
+        }
+        out[(size_t)bi * N + n] = v + f + bsum;
+    }
+}
+
+// read_words = read_weights @ memory (access.py:151)
+__global__ void read_words_kernel(const float* __restrict__ rw, const float* __restrict__ mem, float* __restrict__ out, int N,
+                                  int W, int R) {
+    const int bi = blockIdx.x, b = bi / R;
+    for (int w = threadIdx.x; w < W; w += blockDim.x) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += rw[(size_t)bi * N + n] * mem[((size_t)b * N + n) * W + w];
+        out[(size_t)bi * W + w] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" int ntk_dnc_cosine_weights(const float* memory, const float* keys, const float* strengths, float* out,
@@ -169,4 +260,108 @@ extern "C" int ntk_dnc_write_allocation_weights(const float* usage, const float*
     allocation_kernel<<<B, 1024, (size_t)2 * N * sizeof(float), (hipStream_t)stream>>>(usage, write_gates, out, N, Wn);
     NTK_CHECK_LAUNCH("ntk_dnc_write_allocation_weights");
     return NTK_OK;
+}
+
+extern "C" int ntk_dnc_interface_activations(const float* raw, int ldr, float* act, int B, int N, int W, int R, int Wn,
+                                             void* stream) {
+    NTK_REQUIRE(raw && act, NTK_ERR_BAD_PTR, "ntk_dnc_interface_activations: null pointer");
+    DncDims d;
+    dnc_fill_dims(d, B, 1, N, W, R, Wn, 4, 1, 0.f);
+    NTK_REQUIRE(B > 0 && ldr >= d.I, NTK_ERR_BAD_SHAPE, "ntk_dnc_interface_activations: B=%d ldr=%d (interface %d)", B, ldr, d.I);
+    interface_act_kernel<<<B, 256, 0, (hipStream_t)stream>>>(raw, ldr, act, d);
+    NTK_CHECK_LAUNCH("ntk_dnc_interface_activations");
+    return NTK_OK;
+}
+
+extern "C" int ntk_dnc_write_weights(const float* memory, const float* usage, const float* write_keys, const float* write_strengths,
+                                     const float* allocation_gate, const float* write_gate, float* write_weights,
+                                     float* workspace, int B, int N, int W, int Wn, void* stream) {
+    NTK_REQUIRE(memory && usage && write_keys && write_strengths && allocation_gate && write_gate && write_weights && workspace,
+                NTK_ERR_BAD_PTR, "ntk_dnc_write_weights: null pointer");
+    float* content = workspace;                       // [B,Wn,N]
+    float* alloc = content + (size_t)B * Wn * N;      // [B,Wn,N]
+    float* gates = alloc + (size_t)B * Wn * N;        // [B,Wn]
+    int rc = ntk_dnc_cosine_weights(memory, write_keys, write_strengths, content, B, N, W, Wn, stream);
+    if (rc) return rc;
+    gate_product_kernel<<<(B * Wn + 255) / 256, 256, 0, (hipStream_t)stream>>>(allocation_gate, write_gate, gates, B * Wn);
+    rc = ntk_dnc_write_allocation_weights(usage, gates, alloc, B, N, Wn, stream);
+    if (rc) return rc;
+    write_mix_kernel<<<B * Wn, 256, 0, (hipStream_t)stream>>>(alloc, content, allocation_gate, write_gate, write_weights, N);
+    NTK_CHECK_LAUNCH("ntk_dnc_write_weights");
+    return NTK_OK;
+}
+
+extern "C" int ntk_dnc_erase_and_write(const float* memory, const float* address, const float* reset_weights, const float* values,
+                                       float* out, int B, int N, int W, int Wn, void* stream) {
+    NTK_REQUIRE(memory && address && reset_weights && values && out, NTK_ERR_BAD_PTR, "ntk_dnc_erase_and_write: null pointer");
+    NTK_REQUIRE(B > 0 && N > 0 && W > 0 && Wn > 0, NTK_ERR_BAD_SHAPE, "ntk_dnc_erase_and_write: B=%d N=%d W=%d Wn=%d", B, N, W, Wn);
+    erase_write_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(memory, address, reset_weights, values, out, N, W, Wn);
+    NTK_CHECK_LAUNCH("ntk_dnc_erase_and_write");
+    return NTK_OK;
+}
+
+extern "C" int ntk_dnc_read_weights(const float* memory, const float* prev_read_weights, const float* link, const float* read_keys,
+                                    const float* read_strengths, const float* read_mode, float* read_weights, float* workspace,
+                                    int B, int N, int W, int R, int Wn, void* stream) {
+    NTK_REQUIRE(memory && prev_read_weights && link && read_keys && read_strengths && read_mode && read_weights && workspace,
+                NTK_ERR_BAD_PTR, "ntk_dnc_read_weights: null pointer");
+    float* content = workspace;                        // [B,R,N]
+    float* fwd = content + (size_t)B * R * N;          // [B,R,Wn,N]
+    float* bwd = fwd + (size_t)B * R * Wn * N;         // [B,R,Wn,N]
+    int rc = ntk_dnc_cosine_weights(memory, read_keys, read_strengths, content, B, N, W, R, stream);
+    if (rc) return rc;
+    rc = ntk_dnc_directional_read_weights(link, prev_read_weights, fwd, B, N, Wn, R, 1, stream);
+    if (rc) return rc;
+    rc = ntk_dnc_directional_read_weights(link, prev_read_weights, bwd, B, N, Wn, R, 0, stream);
+    if (rc) return rc;
+    read_mix_kernel<<<B * R, 256, 0, (hipStream_t)stream>>>(content, fwd, bwd, read_mode, read_weights, N, Wn);
+    NTK_CHECK_LAUNCH("ntk_dnc_read_weights");
+    return NTK_OK;
+}
+
+extern "C" int ntk_dnc_read_words(const float* read_weights, const float* memory, float* out, int B, int N, int W, int R,
+                                  void* stream) {
+    NTK_REQUIRE(read_weights && memory && out, NTK_ERR_BAD_PTR, "ntk_dnc_read_words: null pointer");
+    NTK_REQUIRE(B > 0 && N > 0 && W > 0 && R > 0, NTK_ERR_BAD_SHAPE, "ntk_dnc_read_words: B=%d N=%d W=%d R=%d", B, N, W, R);
+    read_words_kernel<<<B * R, 128, 0, (hipStream_t)stream>>>(read_weights, memory, out, N, W, R);
+    NTK_CHECK_LAUNCH("ntk_dnc_read_words");
+    return NTK_OK;
+}
+
+// workspace of ntk_dnc_access_step_fwd: activated interface + the larger of the write / read scratch areas
+extern "C" size_t ntk_dnc_access_step_workspace_bytes(int B, int N, int W, int R, int Wn) {
+    DncDims d;
+    dnc_fill_dims(d, B, 1, N, W, R, Wn, 4, 1, 0.f);
+    const size_t wr = (size_t)2 * B * Wn * N + (size_t)B * Wn, rd = (size_t)B * R * N * (1 + 2 * Wn);
+    return ((size_t)B * d.IP + (wr > rd ? wr : rd)) * sizeof(float);
+}
+
+// MemoryAccess._build (access.py:113-158) from the RAW outputs of the ten interface linears (packed order, row
+// stride ldr): usage -> write weights -> erase/write -> linkage -> read weights -> read words.  Every *_out buffer
+// is distinct from its input (the step reads the previous state while it writes the next).
+extern "C" int ntk_dnc_access_step_fwd(const float* iface_raw, int ldr, const float* memory, const float* read_weights,
+                                       const float* write_weights, const float* link, const float* precedence,
+                                       const float* usage, float* memory_out, float* read_weights_out, float* write_weights_out,
+                                       float* link_out, float* precedence_out, float* usage_out, float* read_words,
+                                       float* workspace, int B, int N, int W, int R, int Wn, void* stream) {
+    NTK_REQUIRE(iface_raw && memory && read_weights && write_weights && link && precedence && usage && memory_out &&
+                    read_weights_out && write_weights_out && link_out && precedence_out && usage_out && read_words && workspace,
+                NTK_ERR_BAD_PTR, "ntk_dnc_access_step_fwd: null pointer");
+    NTK_REQUIRE(memory != memory_out && link != link_out && read_weights != read_weights_out && usage != usage_out,
+                NTK_ERR_BAD_PTR, "ntk_dnc_access_step_fwd: outputs must not alias the previous state");
+    DncDims d;
+    dnc_fill_dims(d, B, 1, N, W, R, Wn, 4, 1, 0.f);
+    float* act = workspace;
+    float* scratch = workspace + (size_t)B * d.IP;
+    auto f = [&](int off) { return act + (size_t)B * off; };
+    int rc = ntk_dnc_interface_activations(iface_raw, ldr, act, B, N, W, R, Wn, stream);
+    if (rc) return rc;
+    if ((rc = ntk_dnc_freeness(write_weights, f(d.oF), read_weights, usage, usage_out, B, N, Wn, R, stream))) return rc;
+    if ((rc = ntk_dnc_write_weights(memory, usage_out, f(d.oKw), f(d.oBw), f(d.oAg), f(d.oWg), write_weights_out, scratch, B, N, W,
+                                    Wn, stream))) return rc;
+    if ((rc = ntk_dnc_erase_and_write(memory, write_weights_out, f(d.oE), f(d.oV), memory_out, B, N, W, Wn, stream))) return rc;
+    if ((rc = ntk_dnc_linkage(link, precedence, write_weights_out, link_out, precedence_out, B, N, Wn, stream))) return rc;
+    if ((rc = ntk_dnc_read_weights(memory_out, read_weights, link_out, f(d.oKr), f(d.oBr), f(d.oRm), read_weights_out, scratch, B,
+                                   N, W, R, Wn, stream))) return rc;
+    return ntk_dnc_read_words(read_weights_out, memory_out, read_words, B, N, W, R, stream);
 }

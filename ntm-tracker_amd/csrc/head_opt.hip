@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void offset_loss_kernel(const float* __restri
     if (tid == 0) {
         float s = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
-        *loss = 0.5f * s;
+        if (loss) *loss = 0.5f * s;
     }
 }
 
@@ -273,7 +273,7 @@ extern "C" int ntk_crop_and_resize(const float* image, int H, int W, int C, cons
 
 extern "C" int ntk_offset_loss(const float* logits, const float* offsets, float* pred, float* loss,
                                float* dlogits, int B, int T, int NF, int O, void* stream) {
-    NTK_REQUIRE(logits && offsets && loss, NTK_ERR_BAD_PTR, "ntk_offset_loss: null pointer");
+    NTK_REQUIRE(logits && offsets && (loss || dlogits), NTK_ERR_BAD_PTR, "ntk_offset_loss: null pointer");
     NTK_REQUIRE(B > 0 && T >= 2 && NF > 0 && O > 0, NTK_ERR_BAD_SHAPE, "ntk_offset_loss: B=%d T=%d NF=%d O=%d (T >= 2)", B, T, NF, O);
     offset_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, offsets, pred, loss, dlogits, B, T, NF, O);
     NTK_CHECK_LAUNCH("ntk_offset_loss");

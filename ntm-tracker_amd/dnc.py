@@ -263,7 +263,11 @@ class DNC(object):
         dgates = torch.empty((B, S, 4 * hid), device=dev)
         dxi = torch.empty((B, S, self.IP), device=dev)
         dypre = torch.empty((B, S, self.OP), device=dev)
-        c = lambda t: _P(t.contiguous())
+        keep = []                                    # contiguous copies stay referenced until the launch is queued
+
+        def c(t):
+            keep.append(t.contiguous())
+            return _P(keep[-1])
         _lib.check(_lib.lib().ntk_dnc_seq_bwd(
             B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value,
             _P(WrT), ldkT, _P(WiT), ldhT, _P(self.Wy),
@@ -428,3 +432,146 @@ class Freeness(object):
     @property
     def state_size(self):
         return (self._memory_size,)
+
+
+class MemoryAccess(object):
+    """dnc/access.py:66-303 -- MemoryAccess(memory_size=128, word_size=20, num_reads=1, num_writes=1), callable on its
+    own: ``module(inputs [B,D], AccessState) -> (read_words [B,R,W], AccessState)``; the reference's tests also call
+    ``_read_inputs``, ``_write_weights`` and ``_read_weights`` directly.  Forward only; parameters carry the Sonnet
+    names ``memory_access/<linear>/{w,b}``.  (Training runs through the fused DNC core.)"""
+
+    def __init__(self, memory_size=128, word_size=20, num_reads=1, num_writes=1, name="memory_access", input_dim=None,
+                 device="cuda", seed=0):
+        self.N, self.W, self.R, self.Wn = int(memory_size), int(word_size), int(num_reads), int(num_writes)
+        self.device, self.seed, self.D = torch.device(device), seed, None
+        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        self.widths = [("write_vectors", Wn * W), ("erase_vectors", Wn * W), ("free_gate", R), ("allocation_gate", Wn),
+                       ("write_gate", Wn), ("read_mode", R * (1 + 2 * Wn)), ("write_keys", Wn * W), ("write_strengths", Wn),
+                       ("read_keys", R * W), ("read_strengths", R)]
+        self.I = sum(w for _, w in self.widths)
+        self.IP = (self.I + 3) // 4 * 4
+        if input_dim is not None:
+            self._build_params(int(input_dim))
+
+    # ---- parameters: the ten snt.Linear modules packed as one [IP][ldx] matrix (row = interface column) + bias
+    def _build_params(self, D, sd=None):
+        self.D, self.ldx = D, (D + 3) // 4 * 4
+        if sd is None:
+            g = torch.Generator().manual_seed(int(self.seed))
+            sd = {}
+            for name, width in self.widths:
+                sd["memory_access/%s/w" % name] = torch.clamp(torch.randn((D, width), generator=g), -2, 2) / D ** 0.5
+                sd["memory_access/%s/b" % name] = torch.zeros(width)
+        self.load_state_dict(sd)
+
+    def load_state_dict(self, sd):
+        t = lambda v: torch.as_tensor(v, dtype=torch.float32)
+        D = t(sd["memory_access/write_vectors/w"]).shape[0]
+        self.D, self.ldx = D, (D + 3) // 4 * 4
+        WT, bias = torch.zeros((self.IP, self.ldx)), torch.zeros(self.IP)
+        o = 0
+        for name, width in self.widths:
+            WT[o:o + width, :D] = t(sd["memory_access/%s/w" % name]).t()
+            bias[o:o + width] = t(sd["memory_access/%s/b" % name])
+            o += width
+        self.WT, self.bias = WT.to(self.device), bias.to(self.device)
+
+    def state_dict(self):
+        out, o = {}, 0
+        for name, width in self.widths:
+            out["memory_access/%s/w" % name] = self.WT[o:o + width, :self.D].t().contiguous().cpu()
+            out["memory_access/%s/b" % name] = self.bias[o:o + width].cpu()
+            o += width
+        return out
+
+    def initial_state(self, batch_size, dtype=torch.float32):
+        z = lambda *s: torch.zeros(s, device=self.device)
+        B, N, W, R, Wn = batch_size, self.N, self.W, self.R, self.Wn
+        return AccessState(z(B, N, W), z(B, R, N), z(B, Wn, N), TemporalLinkageState(z(B, Wn, N, N), z(B, Wn, N)), z(B, N))
+
+    @property
+    def state_size(self):
+        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        return AccessState((N, W), (R, N), (Wn, N), TemporalLinkageState((Wn, N, N), (Wn, N)), (N,))
+
+    @property
+    def output_size(self):
+        return (self.R, self.W)
+
+    def _raw_interface(self, inputs):
+        x = _f32(inputs, self.device)
+        B, D = x.shape
+        if self.D is None:
+            self._build_params(D)
+        if D != self.D:
+            raise _lib.NtkError("inputs have %d features, the module was built for %d" % (D, self.D))
+        X = torch.zeros((B, self.ldx), device=self.device)
+        X[:, :D] = x
+        raw = torch.empty((B, self.IP), device=self.device)
+        _lib.check(_lib.lib().ntk_gemm_nt_f32(_P(X), self.ldx, _P(self.WT), self.ldx, _P(self.bias), _P(raw), self.IP,
+                                              B, self.IP, self.ldx, _lib.stream()), "ntk_gemm_nt_f32")
+        return raw, B
+
+    def _read_inputs(self, inputs):
+        """access.py:160-218 -> dict of activated interface tensors (reference key names)."""
+        raw, B = self._raw_interface(inputs)
+        act = torch.empty(B * self.IP, device=self.device)
+        _lib.check(_lib.lib().ntk_dnc_interface_activations(_P(raw), self.IP, _P(act), B, self.N, self.W, self.R, self.Wn,
+                                                            _lib.stream()), "ntk_dnc_interface_activations")
+        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        shapes = {"write_vectors": (B, Wn, W), "erase_vectors": (B, Wn, W), "free_gate": (B, R), "allocation_gate": (B, Wn),
+                  "write_gate": (B, Wn), "read_mode": (B, R, 1 + 2 * Wn), "write_keys": (B, Wn, W), "write_strengths": (B, Wn),
+                  "read_keys": (B, R, W), "read_strengths": (B, R)}
+        rename = {"write_keys": "write_content_keys", "write_strengths": "write_content_strengths",
+                  "read_keys": "read_content_keys", "read_strengths": "read_content_strengths"}
+        out, o = {}, 0
+        for name, width in self.widths:
+            out[rename.get(name, name)] = act[B * o:B * (o + width)].view(shapes[name])
+            o += width
+        return out
+
+    def _write_weights(self, inputs, memory, usage):
+        """access.py:220-257."""
+        dev = self.device
+        m, u = _f32(memory, dev), _f32(usage, dev)
+        B, N, W = m.shape
+        Wn = self.Wn
+        ws = torch.empty(2 * B * Wn * N + B * Wn, device=dev)
+        out = torch.empty((B, Wn, N), device=dev)
+        # device copies stay referenced until the launch is queued (a temporary's block would be reused by the next one)
+        k, s_ = _f32(inputs["write_content_keys"], dev), _f32(inputs["write_content_strengths"], dev)
+        ag, wg = _f32(inputs["allocation_gate"], dev), _f32(inputs["write_gate"], dev)
+        _lib.check(_lib.lib().ntk_dnc_write_weights(_P(m), _P(u), _P(k), _P(s_), _P(ag), _P(wg), _P(out), _P(ws), B, N, W, Wn,
+                                                    _lib.stream()), "ntk_dnc_write_weights")
+        return out
+
+    def _read_weights(self, inputs, memory, prev_read_weights, link):
+        """access.py:259-303."""
+        dev = self.device
+        m, prw, L = _f32(memory, dev), _f32(prev_read_weights, dev), _f32(link, dev)
+        B, N, W = m.shape
+        R, Wn = self.R, self.Wn
+        ws = torch.empty(B * R * N * (1 + 2 * Wn), device=dev)
+        out = torch.empty((B, R, N), device=dev)
+        k, s_, rm = (_f32(inputs["read_content_keys"], dev), _f32(inputs["read_content_strengths"], dev),
+                     _f32(inputs["read_mode"], dev))
+        _lib.check(_lib.lib().ntk_dnc_read_weights(_P(m), _P(prw), _P(L), _P(k), _P(s_), _P(rm), _P(out), _P(ws), B, N, W, R, Wn,
+                                                   _lib.stream()), "ntk_dnc_read_weights")
+        return out
+
+    def __call__(self, inputs, prev_state):
+        """access.py:113-158 in one C-ABI call (ntk_dnc_access_step_fwd)."""
+        raw, B = self._raw_interface(inputs)
+        dev, L = self.device, _lib.lib()
+        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        c = lambda t: _f32(t, dev)
+        mem, rw, ww = c(prev_state.memory), c(prev_state.read_weights), c(prev_state.write_weights)
+        link, prec, usage = c(prev_state.linkage.link), c(prev_state.linkage.precedence_weights), c(prev_state.usage)
+        e = lambda t: torch.empty_like(t)
+        mem2, rw2, ww2, link2, prec2, usage2 = e(mem), e(rw), e(ww), e(link), e(prec), e(usage)
+        reads = torch.empty((B, R, W), device=dev)
+        ws = torch.empty(L.ntk_dnc_access_step_workspace_bytes(B, N, W, R, Wn) // 4, device=dev)
+        _lib.check(L.ntk_dnc_access_step_fwd(_P(raw), self.IP, _P(mem), _P(rw), _P(ww), _P(link), _P(prec), _P(usage),
+                                             _P(mem2), _P(rw2), _P(ww2), _P(link2), _P(prec2), _P(usage2), _P(reads), _P(ws),
+                                             B, N, W, R, Wn, _lib.stream()), "ntk_dnc_access_step_fwd")
+        return reads, AccessState(mem2, rw2, ww2, TemporalLinkageState(link2, prec2), usage2)

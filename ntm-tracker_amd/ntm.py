@@ -275,14 +275,21 @@ class NTMCell(object):
                 "M": torch.empty((B, S, d.N, d.Md), device=dev), "read": torch.empty((B, S, d.R, d.Md), device=dev),
             }
         g = lambda k: _np(rec.get(k))
-        _lib.check(_lib.lib().ntk_ntm_seq_fwd(
-            B, S, d.N, d.Md, d.R, d.Wh, d.hid, d.shift_range, d.O, 1 if self.write_first else 0,
+        keep = []                                    # contiguous copies stay referenced until the launch is queued
+
+        def cp(t):
+            keep.append(t.contiguous())
+            return _P(keep[-1])
+        # a single step binds the step entry point of the C ABI (same kernel, S = 1)
+        fn, name, lead = ((_lib.lib().ntk_ntm_step_fwd, "ntk_ntm_step_fwd", (B,)) if S == 1 else
+                          (_lib.lib().ntk_ntm_seq_fwd, "ntk_ntm_seq_fwd", (B, S)))
+        _lib.check(fn(
+            *lead, d.N, d.Md, d.R, d.Wh, d.hid, d.shift_range, d.O, 1 if self.write_first else 0,
             _P(xproj), _P(self.params.view("Wr")), _P(self.params.view("Wa")),
-            _P(state["M"].contiguous()), _P(state["w"].contiguous()), _P(state["read"].contiguous()),
-            _P(state["controller_state"].contiguous()),
+            cp(state["M"]), cp(state["w"]), cp(state["read"]), cp(state["controller_state"]),
             _P(logits), _np(outputs), _P(new["M"]), _P(new["w"]), _P(new["read"]), _P(new["controller_state"]),
             g("z"), g("gates"), g("c"), g("h"), g("u"), g("wc"), g("wv"), g("w"), g("M"), g("read"),
-            _lib.stream()), "ntk_ntm_seq_fwd")
+            _lib.stream()), name)
         rec["xproj"] = xproj
         return logits, outputs, new, rec
 
@@ -303,12 +310,17 @@ class NTMCell(object):
         du = torch.empty((B, S, d.PP), device=dev)
         g0 = self.state_placeholder(B)
         df = dfinal or {}
+        keep = []
+
+        def cp(t):
+            keep.append(t.contiguous())
+            return _P(keep[-1])
         _lib.check(L.ntk_ntm_seq_bwd(
             B, S, d.N, d.Md, d.R, d.Wh, d.hid, d.shift_range, d.O, 1 if self.write_first else 0,
             _P(WrT), ldkT, _P(WaT), ldhT,
-            _P(state0["M"].contiguous()), _P(state0["w"].contiguous()), _P(state0["controller_state"].contiguous()),
+            cp(state0["M"]), cp(state0["w"]), cp(state0["controller_state"]),
             _P(rec["gates"]), _P(rec["c"]), _P(rec["u"]), _P(rec["wc"]), _P(rec["wv"]), _P(rec["w"]), _P(rec["M"]),
-            _P(dlogits.contiguous()),
+            cp(dlogits),
             _np(df.get("M")), _np(df.get("w")), _np(df.get("read")), _np(df.get("controller_state")),
             _P(dgates), _P(du), _P(g0["M"]), _P(g0["w"]), _P(g0["read"]), _P(g0["controller_state"]), st),
             "ntk_ntm_seq_bwd")
