@@ -153,6 +153,16 @@ int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int hid, int shi
                     float* dgates, float* du, float* dM0, float* dw0, float* dread0, float* dcs0,
                     void* stream);
 
+/* Stand-alone addressing ops (ops.py, called by ops_test.py): batched_smooth_cosine_similarity (:135-158) --
+ * mode 0 = as coded (quirk Q1: feature columns normalised over the slot axis; what NTMCell computes),
+ * mode 1 = true smooth cosine dot/(|m||k| + 1e-3) (what ops_test.py:20-34 pins); memory [B,N,Md], keys [B,H,Md],
+ * out [B,H,N].  batched_circular_convolution (:180-214) with the Python-2 taps (quirk Q2): w [B,H,N],
+ * kernel [B,H,shift_space]. */
+int ntk_ntm_cosine_similarity(const float* memory, const float* keys, float* out, int B, int N, int Md, int H,
+                              int mode, void* stream);
+int ntk_ntm_circular_convolution(const float* w, const float* kernel, float* out, int B, int H, int N, int shift_space,
+                                 void* stream);
+
 /* One step of the cell (ntk_ntm_step_fwd/bwd) = the sequence kernels with S = 1; argument meaning as
  * ntk_ntm_seq_fwd / ntk_ntm_seq_bwd (the state AFTER the step takes the place of the final state). */
 int ntk_ntm_step_fwd(int B, int N, int Md, int R, int Wh, int hid, int shift_range, int O, int write_first,

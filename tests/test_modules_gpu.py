@@ -225,3 +225,44 @@ def test_ntm_step_entry_point_equals_sequence_kernel(cuda):
         state = r[2]
     np.testing.assert_array_equal(torch.stack(outs, 1).cpu().numpy(), logits_seq.cpu().numpy())
     np.testing.assert_array_equal(state["M"].cpu().numpy(), new_seq["M"].cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ops.py module functions (ops_test.py)
+# ---------------------------------------------------------------------------------------------------------
+def test_ops_cosine_similarity_golden_vectors(cuda):
+    """ops_test.py:20-34 pins TRUE smooth cosine (opt-in mode); the as-coded values (quirk Q1, the mode NTMCell uses) are
+    the hand-evaluated vector of tests/golden/reference_vectors.json -- the reference's own test FAILS against its code."""
+    import json, os
+    from ntmtrack import ops
+    from oracle import ntm_oracle as O
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+    t7 = [v for k, v in vec.items() if k.startswith("ops_test.py")][0]
+    coded = [v for k, v in vec.items() if k.startswith("ops.py:147")][0]
+    mem, keys = np.array(t7["memory"], np.float32), np.array(t7["keys"], np.float32)
+    got_true = ops.batched_smooth_cosine_similarity(mem, keys, similarity="smooth_cosine", device=cuda).cpu().numpy()
+    np.testing.assert_allclose(got_true, np.array(t7["expected"]), atol=1e-4)
+    got = ops.batched_smooth_cosine_similarity(mem, keys, device=cuda).cpu().numpy()
+    np.testing.assert_allclose(got, np.array(coded["expected"]), atol=1e-4)
+    assert np.abs(got - np.array(t7["expected"])).max() > 0.05          # Q1: the shipped code is not the tested function
+    rng = np.random.default_rng(0)
+    mem, keys = rng.standard_normal((3, 128, 20)).astype(np.float32), rng.standard_normal((3, 5, 20)).astype(np.float32)
+    for mode in ("as_coded", "smooth_cosine"):
+        got = ops.batched_smooth_cosine_similarity(mem, keys, similarity=mode, device=cuda).cpu().numpy()
+        np.testing.assert_allclose(got, O.batched_smooth_cosine_similarity(mem, keys, mode), atol=2e-6)
+
+
+def test_ops_circular_convolution_and_shift(cuda):
+    from ntmtrack import ops
+    from oracle import ntm_oracle as O
+    rng = np.random.default_rng(1)
+    w = rng.random((2, 5, 128)).astype(np.float32)
+    for SS in (3, 5, 1):
+        s = rng.random((2, 5, SS)).astype(np.float32)
+        got = ops.batched_circular_convolution(w, s, device=cuda).cpu().numpy()
+        np.testing.assert_allclose(got, O.batched_circular_convolution(w, s), atol=1e-6)
+    # Q2: a one-hot kernel on the LAST tap is the identity (taps are -2,-1,0, not -1,0,1)
+    ident = np.zeros((2, 5, 3), np.float32); ident[..., 2] = 1
+    np.testing.assert_array_equal(ops.batched_circular_convolution(w, ident, device=cuda).cpu().numpy(), w)
+    for shift in (-2, -1, 0, 1, 3):
+        np.testing.assert_array_equal(ops.circular_shift(w, shift, device=cuda).cpu().numpy(), O.circular_shift(w, shift))
