@@ -71,6 +71,15 @@ int ntk_vgg_conv3x3_relu_bf16(const void* in_bf16, const void* w_packed_bf16, co
 int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, const float* bias, void* out_bf16,
                                      int frames, int H, int W, int cin, int cout, void* stream);
 
+/* The same operator by fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (2.25x fewer multiplies; results equal to
+ * ntk_vgg_conv3x3_relu_f32 up to rounding, ~1e-6 relative per layer).  Weights: U = G g G^T for the 16 transform
+ * planes, packed lane-major for the MFMA B operand (ntk_vgg_wino_packed_floats(cin, cout) = 16*cin*cout floats).
+ * cin a multiple of 16, cout a multiple of 64 (64, 128, 256 or a multiple of 512), H a multiple of 4, W of 28. */
+size_t ntk_vgg_wino_packed_floats(int cin, int cout);
+int ntk_vgg_pack_weights_wino(const float* w_hwio, float* u_packed, int cin, int cout, void* stream);
+int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                  int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream);
+
 /* slim.max_pool2d [2,2] stride 2 on NHWC fp32 (vgg.py:155-161) as its own launch (ntk_maxpool2x2).
  * The trunk fuses the pool into the epilogue of conv1_2 / conv2_2 / conv3_3 (fuse_pool); this entry point is the
  * un-fused form with identical results.  H, W even; C a multiple of 4. */
