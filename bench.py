@@ -27,7 +27,7 @@ import torch
 # HBM-side bytes of one VGG trunk pass over 640 frames (10 conv launches): rocprofv3 --pmc FETCH_SIZE (x2: gfx950
 # counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv.
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
-TRUNK_TRAFFIC_BYTES_640_FRAMES = 5.4737e10 + 2.3121e10
+TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd": None}
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--model", default="ntm", choices=["ntm", "dnc"],
                     help="ntm = BASELINE configs[1] (the headline metric); dnc = configs[2] (DNC 256x64, 4 read heads), reported for reference")
+    ap.add_argument("--conv-algo", default="winograd", choices=["winograd", "direct"],
+                    help="fp32 trunk: fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (default) or the direct implicit-GEMM kernel")
     ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact fp32 MFMA (configs 2-4, the headline); bf16 = bf16 operands / fp32 accumulate (config 5)")
     ap.add_argument("--mem-size", type=int, default=None)
@@ -177,9 +179,9 @@ def main():
     ws = vgg_weights(42)
     if args.model == "dnc":
         trk = tracker.DNCOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, mem_size=args.mem_size or 256,
-                                       mem_dim=args.mem_dim or 64, conv_dtype=args.conv_dtype)
+                                       mem_dim=args.mem_dim or 64, conv_dtype=args.conv_dtype, conv_algo=args.conv_algo)
     else:
-        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, conv_dtype=args.conv_dtype)   # same init on every rank
+        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, conv_dtype=args.conv_dtype, conv_algo=args.conv_algo)   # same init on every rank
     log("tracker built; generating synthetic inputs")
     frames, gts0, offs = synth_inputs(B, T, dev, 42 + rank)
     log("inputs resident in HBM: frames %s" % (tuple(frames.shape),))
@@ -274,13 +276,19 @@ def main():
                                     % (4 if trk.core.N >= 512 else 2, trk.core.N, trk.core.W, "training" if args.mode == "train" else "inference", B, T)),
                        "global_batch": world * B, "seq_len": T, "steps_per_sequence": T * 65,
                        "parallelism": "dp%d" % world, "mode": args.mode},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_relu_kernel (VGG trunk, 10 layers)" if args.conv_dtype == "f32"
-                         else "conv3x3_relu_bf16_kernel (VGG trunk, 10 layers)",
+            "roofline": {"bound": "mfma", "kernel": (("conv3x3_wino_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(2x2,3x3) layers)"
+                                                      if args.conv_algo == "winograd" else "conv3x3_relu_dma_kernel (VGG trunk, 10 layers)")
+                                                     if args.conv_dtype == "f32" else "conv3x3_relu_bf16_kernel (VGG trunk, 10 layers)"),
                          "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4),
-                         "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES * (B * T) / 640.0) if args.conv_dtype == "f32" else None,
+                         "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo] * (B * T) / 640.0)
+                         if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo]) else None,
                          "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
-                         "algorithmic_flops_per_frame": conv_flops_per_frame()},
+                         "algorithmic_flops_per_frame": conv_flops_per_frame(),
+                         "note": ("achieved = ALGORITHMIC direct-convolution flops (SURVEY 8d: 27.92 GFLOP/frame, independent of the "
+                                  "algorithm) / trunk time; the Winograd kernel executes 2.25x fewer multiplies on 28 of 32 MFMA rows "
+                                  "(executed MFMA flops = algorithmic x 0.508), so frac may exceed 1 against the fp32 MFMA peak")
+                                 if (args.conv_algo == "winograd" and args.conv_dtype == "f32") else "direct convolution: executed = algorithmic flops"},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},
         }

@@ -160,11 +160,11 @@ class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  num_layers=1, read_head_size=4, write_head_size=1, write_first=False, init_scale=0.05,
                  learning_rate=1e-4, decay=0.95, momentum=0.9, max_gradient_norm=5.0, feature_channels=512,
-                 device="cuda", seed=42, vgg_chunk_frames=1024, conv_dtype="f32"):
+                 device="cuda", seed=42, vgg_chunk_frames=1024, conv_dtype="f32", conv_algo="winograd"):
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
-        self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype) if vgg_weights else None
+        self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
         self.cell = NTMCell(2, mem_size=mem_size, mem_dim=mem_dim, controller_hidden_size=hidden_size,
                             controller_num_layers=num_layers, write_head_size=write_head_size,
                             read_head_size=read_head_size, write_first=write_first,
@@ -226,12 +226,12 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  read_head_size=4, write_head_size=1, clip_value=20, feature_channels=512, device="cuda", seed=42,
                  vgg_chunk_frames=1024, learning_rate=1e-4, optimizer_epsilon=1e-10, max_gradient_norm=50.0,
-                 conv_dtype="f32"):
+                 conv_dtype="f32", conv_algo="winograd"):
         from .dnc import DNC
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
-        self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype) if vgg_weights else None
+        self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
         self.core = DNC({"memory_size": mem_size, "word_size": mem_dim, "num_reads": read_head_size,
                          "num_writes": write_head_size}, {"hidden_size": hidden_size}, 2, clip_value,
                         input_dim=feature_channels + 2, device=self.device, seed=seed)

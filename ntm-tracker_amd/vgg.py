@@ -118,13 +118,19 @@ class VGG16Conv43(object):
     conv1_1 reads the fp32 frames, conv4_3 writes fp32 for the memory cell).
     """
 
-    def __init__(self, weights, device="cuda", chunk_frames=1024, dtype="f32"):
+    def __init__(self, weights, device="cuda", chunk_frames=1024, dtype="f32", algo="winograd"):
         self.device = torch.device(device)
         self.chunk_frames = int(chunk_frames)
         if dtype not in ("f32", "bf16"):
             raise _lib.NtkError("VGG16Conv43: dtype must be 'f32' or 'bf16'")
+        if algo not in ("winograd", "direct"):
+            raise _lib.NtkError("VGG16Conv43: algo must be 'winograd' or 'direct'")
         self.dtype = dtype
+        # fp32 trunk: fused Winograd F(2x2,3x3) wherever the layer shape allows (conv1_2 .. conv4_3 on 224x224 frames),
+        # the direct implicit-GEMM kernel otherwise (conv1_1, odd frame sizes); "direct" forces the latter everywhere
+        self.algo = algo
         self.packed = {}
+        self.packed_wino = {}
         for name, cin, cout, _pool in VGG_LAYERS:
             w, b = weights[name]
             w = torch.as_tensor(w, dtype=torch.float32).to(self.device)
@@ -135,6 +141,8 @@ class VGG16Conv43(object):
                 self.packed[name] = (pack_weights_bf16(w), b)
             else:
                 self.packed[name] = (pack_weights(w), b)
+                if dtype == "f32" and algo == "winograd" and cin % 16 == 0:
+                    self.packed_wino[name] = pack_weights_wino(w)
 
     def _forward_chunk_bf16(self, frames, out=None):
         F, H, W, _ = frames.shape
@@ -158,7 +166,11 @@ class VGG16Conv43(object):
         for name, cin, cout, pool in VGG_LAYERS:
             wp, b = self.packed[name]
             last = (name == upto)
-            x = conv3x3_relu(x, wp, b, cin, cout, fuse_pool=(pool and not last), out=out if last else None)
+            if name in self.packed_wino and wino_supported(cin, cout, x.shape[1], x.shape[2]):
+                x = conv3x3_relu_wino(x, self.packed_wino[name], b, cin, cout, fuse_pool=(pool and not last),
+                                      out=out if last else None)
+            else:
+                x = conv3x3_relu(x, wp, b, cin, cout, fuse_pool=(pool and not last), out=out if last else None)
             if last:
                 break
         return x

@@ -113,3 +113,55 @@ def test_vgg_trunk_bf16_matches_bf16_oracle(cuda):
     assert np.max(np.abs(got - ref)) / scale < 2e-2
     # and the bf16 trunk stays within ~1 % of the fp32 trunk (the stated tolerance of config 5's conv)
     assert np.max(np.abs(got - ref32)) / np.max(np.abs(ref32)) < 3e-2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip): same operator, tolerance-level parity with the oracle
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("F,H,W,cin,cout,pool", [
+    (2, 8, 28, 16, 64, False),      # smallest legal block, one K iteration
+    (2, 8, 28, 64, 64, True),       # conv1_2-like: one column block, fused pool
+    (1, 28, 28, 128, 128, False),   # two column blocks (4 XCDs each)
+    (3, 12, 56, 32, 256, True),     # four column blocks, two blocks per row, ragged XCD groups
+    (1, 28, 28, 64, 512, False),    # eight column blocks = one per XCD
+    (1, 4, 28, 32, 1024, False),    # sixteen column blocks (two per XCD)
+])
+def test_conv3x3_relu_winograd_matches_oracle(cuda, F, H, W, cin, cout, pool):
+    from ntmtrack import vgg
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((F, H, W, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    ref = O.conv3x3_same_relu(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    if pool:
+        ref = O.maxpool2x2(ref)
+    assert vgg.wino_supported(cin, cout, H, W)
+    up = vgg.pack_weights_wino(torch.from_numpy(w).to(cuda))
+    got = vgg.conv3x3_relu_wino(torch.from_numpy(x).to(cuda), up, torch.from_numpy(b).to(cuda), cin, cout, fuse_pool=pool).cpu().numpy()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 1e-5
+
+
+def test_winograd_rejects_bad_shapes(cuda):
+    from ntmtrack import vgg, _lib
+    b = torch.zeros(64, device=cuda)
+    u = torch.zeros(16 * 32 * 64, device=cuda)
+    with pytest.raises(_lib.NtkError):
+        vgg.conv3x3_relu_wino(torch.zeros((1, 8, 32, 32), device=cuda), u, b, 32, 64)      # W not a multiple of 28
+    with pytest.raises(_lib.NtkError):
+        vgg.conv3x3_relu_wino(torch.zeros((1, 6, 28, 32), device=cuda), u, b, 32, 64)      # H not a multiple of 4
+    assert not vgg.wino_supported(3, 64, 224, 224) and not vgg.wino_supported(64, 192, 224, 224)
+
+
+def test_vgg_trunk_winograd_equals_direct_fullsize(cuda):
+    """The default fp32 trunk (conv1_1 direct + nine Winograd layers) against the all-direct trunk on 224x224 frames:
+    both are fp32 with different summation orders; they agree to 1e-5 of the activation scale through ten layers."""
+    from ntmtrack import vgg
+    rng = np.random.default_rng(5)
+    ws = O.init_vgg_weights(rng)
+    frames = torch.from_numpy((rng.uniform(0, 255, size=(2, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)).to(cuda)
+    a = vgg.VGG16Conv43(ws, device=cuda, algo="winograd")
+    d = vgg.VGG16Conv43(ws, device=cuda, algo="direct")
+    assert len(a.packed_wino) == 9 and not d.packed_wino
+    ya, yd = a(frames).cpu().numpy(), d(frames).cpu().numpy()
+    assert _rel(ya, yd) < 1e-5
