@@ -228,9 +228,9 @@ def main():
         # K steps = K VGG passes + K NTM passes; VGG(i+1) is in flight while NTM(i) runs
         submit(timed)
         for i in range(k):
+            consume(timed)              # enqueue the core pass of batch i (waits for its features on the GPU) ...
             if i + 1 < k:
-                submit(timed)
-            consume(timed)
+                submit(timed)           # ... then the trunk of batch i+1, which starts after batch i's input projection
         trk.join()
 
     if args.warmup > 0:

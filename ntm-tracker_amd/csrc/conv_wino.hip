@@ -23,11 +23,9 @@ namespace {
 
 constexpr int WT = 256;            // threads
 constexpr int KC = 16;             // input channels per K iteration
-constexpr int TW = 14, TH = 2;     // tiles per workgroup: 14 wide x 2 tall
-constexpr int NTILE = TW * TH;     // 28 (of 32 MFMA rows)
-constexpr int PW = 2 * TW + 2;     // 30 patch columns
-constexpr int PH = 2 * TH + 2;     // 6 patch rows
-constexpr int NPX = PW * PH;       // 180 patch pixels
+// tiles per workgroup: 14 wide x 2 tall (28 of the 32 MFMA rows; fits every VGG layer) or 8 x 4 (all 32 rows; layers
+// whose tile grid is a multiple of 8 x 4: conv1_2, conv2_x).  Both patches are 180 pixels (6 x 30 or 10 x 18).
+constexpr int NPX = 180;
 constexpr int RS = 20;             // LDS row stride (floats) of a 16-channel row: conflict-free ds_read_b128
 constexpr int BNW = 64;            // output channels per workgroup
 
@@ -36,7 +34,7 @@ struct WinoArgs {
     const float* in; const float* U; const float* bias; float* out;
     int frames, H, W, Cin, Cout;
     int nCB;            // Cout / 64
-    int bxN, byN;       // workgroup blocks per frame: W/28, H/4
+    int bxN, byN;       // workgroup blocks per frame: W/(2 TW), H/(2 TH)
     int NS;             // spatial blocks = frames * byN * bxN
 };
 
@@ -66,8 +64,10 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <bool POOL>
+template <bool POOL, int TW, int TH>
 __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
+    constexpr int NTILE = TW * TH, PW = 2 * TW + 2, PH = 2 * TH + 2;
+    static_assert(PW * PH == NPX && NTILE <= 32, "patch must be 180 pixels");
     __shared__ __attribute__((aligned(16))) float s_raw[NPX * RS];          // 14.4 KB  [pixel][16 ch]
     __shared__ __attribute__((aligned(16))) float s_V[16 * 32 * RS];        // 40 KB    [plane][tile][16 ch]
 
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     const int by = t1 % a.byN;
     const int f = t1 / a.byN;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-    const int y0 = 4 * by - 1, x0 = 28 * bx - 1;        // top-left of the input patch
+    const int y0 = 2 * TH * by - 1, x0 = 2 * TW * bx - 1;        // top-left of the input patch
 
     // ---- patch staging: 180 pixels x 4 float4 = 720 float4 slots, 3 per thread (the last one partial)
     const float* src[3];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
             }
             if (m < NTILE) {
                 const int tr = m / TW, tc = m - tr * TW;
-                const int oy = 4 * by + 2 * tr, ox = 28 * bx + 2 * tc;
+                const int oy = 2 * TH * by + 2 * tr, ox = 2 * TW * bx + 2 * tc;
                 if constexpr (POOL) {
                     const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
                     a.out[(((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n] = fmaxf(v + bv, 0.f);
@@ -284,14 +284,19 @@ extern "C" int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_pac
     NTK_REQUIRE(in && u_packed && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_wino_f32: null pointer");
     NTK_REQUIRE(ntk_aligned16(in) && ntk_aligned16(u_packed) && ntk_aligned16(out), NTK_ERR_BAD_PTR,
                 "ntk_vgg_conv3x3_relu_wino_f32: 16-byte alignment");
-    NTK_REQUIRE(frames > 0 && H >= 4 && (H % 4) == 0 && W >= 28 && (W % 28) == 0, NTK_ERR_UNSUPPORTED,
-                "ntk_vgg_conv3x3_relu_wino_f32: frames=%d H=%d (multiple of 4) W=%d (multiple of 28)", frames, H, W);
+    NTK_REQUIRE(frames > 0 && ((H >= 4 && (H % 4) == 0 && W >= 28 && (W % 28) == 0) || (H >= 8 && (H % 8) == 0 && (W % 16) == 0)),
+                NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino_f32: frames=%d H=%d W=%d (H %% 4 == 0 and W %% 28 == 0, or H %% 8 == 0 and W %% 16 == 0)",
+                frames, H, W);
     NTK_REQUIRE(cin >= KC && (cin % KC) == 0 && cout >= BNW && (cout % BNW) == 0, NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_wino_f32: cin=%d (multiple of 16) cout=%d (multiple of 64)", cin, cout);
     WinoArgs a;
     a.in = in; a.U = u_packed; a.bias = bias; a.out = out;
     a.frames = frames; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
-    a.nCB = cout / BNW; a.bxN = W / 28; a.byN = H / 4;
+    const bool wide = (W % 16) == 0 && (H % 8) == 0;          // 8 x 4 tile blocks: every MFMA row used
+    a.nCB = cout / BNW;
+    a.bxN = wide ? W / 16 : W / 28;
+    a.byN = wide ? H / 8 : H / 4;
     const long long NS = (long long)frames * a.byN * a.bxN;
     NTK_REQUIRE(NS < (1ll << 30) && (a.nCB <= 8 ? (8 % a.nCB) == 0 : (a.nCB % 8) == 0), NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_wino_f32: cout/64=%d must divide or be a multiple of 8", a.nCB);
@@ -301,8 +306,13 @@ extern "C" int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_pac
     else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
     const long long grid = slots * 8;
     NTK_REQUIRE(grid < (1ll << 31), NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino_f32: grid too large");
-    if (fuse_pool) conv3x3_wino_kernel<true><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
-    else conv3x3_wino_kernel<false><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+    if (wide) {
+        if (fuse_pool) conv3x3_wino_kernel<true, 8, 4><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_wino_kernel<false, 8, 4><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+    } else {
+        if (fuse_pool) conv3x3_wino_kernel<true, 14, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_wino_kernel<false, 14, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+    }
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_wino_f32");
     return NTK_OK;
 }

@@ -256,12 +256,16 @@ class NTMCell(object):
         X[:, :, :D] = inputs
         return X
 
-    def run_sequence(self, X, state, record=False, want_outputs=True):
-        """X [B,S,ldx] (zero padded beyond D).  Returns (logits, outputs, new_state, record dict)."""
+    def run_sequence(self, X, state, record=False, want_outputs=True, after_projection=None):
+        """X [B,S,ldx] (zero padded beyond D).  Returns (logits, outputs, new_state, record dict).
+        after_projection: optional callable invoked once the input projection GEMM has been enqueued (the
+        two-stream pipeline records an event there, see tracker._TwoStreamPipeline)."""
         d, dev = self.dims, self.device
         B, S, ldx = X.shape
         assert ldx == d.ldx
         xproj = gemm_nt(X.view(B * S, ldx), self.params.view("WxT"))
+        if after_projection is not None:
+            after_projection()
         logits = torch.empty((B, S, d.O), device=dev)
         outputs = torch.empty((B, S, d.O), device=dev) if want_outputs else None
         new = self.state_placeholder(B)

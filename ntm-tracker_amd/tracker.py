@@ -104,6 +104,16 @@ class _TwoStreamPipeline(object):
         self._s_ntm = None
         self._slots = []
         self._pending = []
+        self._next_slot = 0
+        self._proj_done = None      # event: input projection of the batch being trained is enqueued/done
+
+    def _mark_projection(self):
+        """Called by the core's forward pass right after the input-projection GEMM: the next trunk pass waits for
+        this point, so the (tiny, parameter-dependent) projection at the head of the strictly serial recurrent
+        chain runs on an idle chip instead of queueing behind the HBM-bound conv1_1 of the next batch."""
+        if self._s_ntm is not None:
+            self._proj_done = torch.cuda.Event()
+            self._proj_done.record(torch.cuda.current_stream(self.device))
 
     def _streams(self):
         if self._s_vgg is None:
@@ -121,9 +131,12 @@ class _TwoStreamPipeline(object):
         if not self._slots:
             self._slots = [dict(buf=torch.empty((F, frames.shape[1] // 8, frames.shape[2] // 8, 512), device=self.device),
                                 free=None) for _ in range(2)]
-        busy = [id(p[0]) for p in self._pending]
-        slot = next(sl for sl in self._slots if id(sl) not in busy)
+        slot = self._slots[self._next_slot]          # strict alternation: never the buffer the core pass may still be reading
+        self._next_slot ^= 1
         s_vgg.wait_stream(torch.cuda.current_stream(self.device))       # frames were produced on the caller's stream
+        if self._proj_done is not None:
+            s_vgg.wait_event(self._proj_done)                            # see _mark_projection (no-op if already passed)
+            self._proj_done = None
         if slot["free"] is not None:
             s_vgg.wait_event(slot["free"])                               # core pass that last read this buffer is done
         with torch.cuda.stream(s_vgg):
@@ -133,7 +146,9 @@ class _TwoStreamPipeline(object):
         self._pending.append((slot, done))
 
     def train_on_submitted(self, gts0, offsets):
-        """Core forward + BPTT + (all-reduce) + optimiser on the oldest submitted feature batch."""
+        """Core forward + BPTT + (all-reduce) + optimiser on the oldest submitted feature batch.
+        Call it BEFORE submit_features() of the following batch: both only enqueue work, and the next trunk pass
+        then starts right after this batch's input projection (see _mark_projection)."""
         _, s_ntm = self._streams()
         slot, done = self._pending.pop(0)
         s_ntm.wait_stream(torch.cuda.current_stream(self.device))
@@ -184,7 +199,8 @@ class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def forward_features(self, fmap, gts0, record=False):
         X = self.serialize(fmap, gts0)
         st0 = self.cell.zero_state(self.B)
-        logits, _outs, new, rec = self.cell.run_sequence(X, st0, record=record, want_outputs=False)
+        logits, _outs, new, rec = self.cell.run_sequence(X, st0, record=record, want_outputs=False,
+                                                         after_projection=self._mark_projection)
         return X, st0, logits, rec
 
     def infer(self, frames, gts0):
@@ -250,6 +266,7 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         from .ntm import gemm_nt
         X = gather_serialize(fmap, gts0, self.B, self.T, self.core.ldx)
         xproj = gemm_nt(X.view(self.B * self.S, self.core.ldx), self.core.WxT)
+        self._mark_projection()
         out_tm, state = self.core.run_projected(xproj, self.B, self.S, record=record)
         self._X = X
         return out_tm.transpose(0, 1).contiguous(), state

@@ -30,7 +30,7 @@ def check(F, H, W, cin, cout, pool):
 if len(sys.argv) > 1 and sys.argv[1] == "check":
     bad = 0
     for cfg in [(2, 8, 28, 32, 64, False), (2, 8, 28, 64, 64, True), (1, 28, 28, 128, 128, False), (3, 12, 56, 32, 256, True),
-                (1, 28, 28, 64, 512, False)]:
+                (1, 28, 28, 64, 512, False), (2, 8, 16, 32, 64, False), (1, 16, 48, 64, 128, True), (1, 112, 112, 64, 128, False)]:
         bad += check(*cfg) > 1e-4
     print("BAD" if bad else "OK")
     sys.exit(1 if bad else 0)

@@ -125,6 +125,8 @@ def test_vgg_trunk_bf16_matches_bf16_oracle(cuda):
     (3, 12, 56, 32, 256, True),     # four column blocks, two blocks per row, ragged XCD groups
     (1, 28, 28, 64, 512, False),    # eight column blocks = one per XCD
     (1, 4, 28, 32, 1024, False),    # sixteen column blocks (two per XCD)
+    (2, 8, 16, 32, 64, False),      # 8x4 tile blocks (all 32 MFMA rows): smallest
+    (1, 16, 48, 64, 128, True),     # 8x4 tile blocks, several blocks per row, fused pool
 ])
 def test_conv3x3_relu_winograd_matches_oracle(cuda, F, H, W, cin, cout, pool):
     from ntmtrack import vgg
@@ -147,7 +149,7 @@ def test_winograd_rejects_bad_shapes(cuda):
     b = torch.zeros(64, device=cuda)
     u = torch.zeros(16 * 32 * 64, device=cuda)
     with pytest.raises(_lib.NtkError):
-        vgg.conv3x3_relu_wino(torch.zeros((1, 8, 32, 32), device=cuda), u, b, 32, 64)      # W not a multiple of 28
+        vgg.conv3x3_relu_wino(torch.zeros((1, 8, 40, 32), device=cuda), u, b, 32, 64)      # W neither a multiple of 28 nor of 16
     with pytest.raises(_lib.NtkError):
         vgg.conv3x3_relu_wino(torch.zeros((1, 6, 28, 32), device=cuda), u, b, 32, 64)      # H not a multiple of 4
     assert not vgg.wino_supported(3, 64, 224, 224) and not vgg.wino_supported(64, 192, 224, 224)
