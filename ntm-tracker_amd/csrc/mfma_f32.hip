@@ -793,6 +793,68 @@ extern "C" int ntk_vgg_set_conv_variant(int v) {
     return NTK_OK;
 }
 
+namespace {
+// ---------------------------------------------------------------------------
+// conv1_1 (Cin = 3 -> Cout = 64, no pool): dedicated persistent kernel.  The layer is bound by its 12.8 MB/frame
+// of output stores, not by its 27-deep contraction, so the generic tile kernel's per-workgroup set-up (250 000
+// workgroups for a 640-frame batch) is what it pays for.  Here a wave owns 32 consecutive pixels of one image row x
+// all 64 channels: K = 27 (+1 zero) = 14 steps of v_mfma_f32_32x32x2_f32 x 2 column blocks, the A operand gathered
+// straight from the 3-channel frame (L1 hits: every input value is used by 9 taps of 3 rows), the 28 x 64 weights
+// resident in registers for the whole kernel, and waves stride over the row segments of the batch.
+// Same arithmetic as the tile kernel: a k-ordered fp32 MFMA chain over k = tap * 3 + c.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void conv_c3_rows_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int nseg, int H, int W) {
+    const int lane = threadIdx.x & 63, m = lane & 31, kh = lane >> 5;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    float b0[14], b1[14];
+    int off[14], dyv[14], dxv[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int k = 2 * s + kh;                       // < 28; k = 27 is the zero pad column of the packed weights
+        b0[s] = wp[m * 32 + k];
+        b1[s] = wp[(32 + m) * 32 + k];
+        const int tap = k / 3, c = k - tap * 3;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        dyv[s] = (k < 27) ? dy : 4;                     // 4: never inside the image
+        dxv[s] = dx;
+        off[s] = (dy * W + dx) * 3 + c;
+    }
+    const float bv0 = bias[m], bv1 = bias[32 + m];
+    const int spr = W >> 5;                             // 32-pixel segments per row
+    for (int seg = gw; seg < nseg; seg += nw) {
+        const int xs = seg % spr;
+        const int t = seg / spr;
+        const int y = t % H;                            // t = f * H + y
+        const int x = xs * 32 + m;
+        const float* base = in + ((size_t)t * W + x) * 3;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        float av[14];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int yy = y + dyv[s], xx = x + dxv[s];
+            av[s] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? base[off[s]] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b1[s], acc1, 0, 0, 0);
+        }
+        float* orow = out + ((size_t)t * W + xs * 32) * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = 4 * kh + (r & 3) + 8 * (r >> 2);
+            orow[(size_t)mm * 64 + m] = fmaxf(acc0[r] + bv0, 0.f);
+            orow[(size_t)mm * 64 + 32 + m] = fmaxf(acc1[r] + bv1, 0.f);
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, const float* bias,
                                         float* out, int frames, int H, int W, int cin, int cout,
                                         int fuse_pool, void* stream) {
@@ -814,7 +876,12 @@ extern "C" int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, 
     const int Kp = ntk_vgg_packed_k(cin);
     hipStream_t st = (hipStream_t)stream;
     const bool bn128 = (cout % 128) == 0;
-    if (smallc) {
+    if (cin == 3 && cout == 64 && !fuse_pool && (W % 32) == 0 && g_conv_variant >= 4) {
+        const long nseg = (long)frames * H * (W / 32);
+        NTK_REQUIRE(nseg < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32: %ld row segments", nseg);
+        const int wgs = (int)((nseg + 3) / 4 < 1024 ? (nseg + 3) / 4 : 1024);      // 256 CUs x 4 workgroups, waves stride over segments
+        conv_c3_rows_kernel<<<wgs, 256, 0, st>>>(in, w_packed, bias, out, (int)nseg, H, W);
+    } else if (smallc) {
         if (bn128) launch_conv<128, true>(in, w_packed, bias, out, npatch, H, W, cin, cout, Kp, fuse_pool, st);
         else launch_conv<64, true>(in, w_packed, bias, out, npatch, H, W, cin, cout, Kp, fuse_pool, st);
     } else {

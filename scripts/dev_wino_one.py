@@ -1,0 +1,14 @@
+"""Dev: a few launches of one Winograd layer shape (for rocprofv3 --pmc)."""
+import sys, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntmtrack import vgg
+dev = torch.device("cuda")
+F, H, cin, cout = int(sys.argv[1]) if len(sys.argv) > 1 else 640, 56, 256, 256
+x = torch.randn((F, H, H, cin), device=dev)
+w = torch.randn((3, 3, cin, cout), device=dev) * 0.02
+b = torch.zeros(cout, device=dev)
+up = vgg.pack_weights_wino(w)
+out = torch.empty((F, H, H, cout), device=dev)
+for _ in range(3):
+    vgg.conv3x3_relu_wino(x, up, b, cin, cout, out=out)
+torch.cuda.synchronize()

@@ -15,6 +15,8 @@ def _rel(a, b):
 @pytest.mark.parametrize("F,H,W,cin,cout,pool", [
     (2, 8, 12, 3, 64, False),      # conv1_1 path (tiny Cin, scalar gather loader)
     (1, 16, 16, 3, 64, True),
+    (2, 8, 32, 3, 64, False),      # conv1_1 dedicated persistent row kernel (W a multiple of 32, no pool)
+    (1, 4, 96, 3, 64, False),
     (3, 8, 8, 64, 64, True),       # BN=64 tile, fused pool
     (2, 12, 8, 64, 128, False),    # BN=128 tile
     (1, 28, 28, 256, 512, False),  # conv4_1 shape, one frame (ragged last row-tile: 784 = 6*128+16)
