@@ -25,9 +25,10 @@ import numpy as np
 import torch
 
 # HBM-side bytes of one VGG trunk pass over 640 frames (10 conv launches): rocprofv3 --pmc FETCH_SIZE (x2: gfx950
-# counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv.
+# counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv
+# (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
-TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd": None}
+TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd": 8.3395e10 + 2.3121e10}
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
@@ -283,7 +284,7 @@ def main():
                          "frac": round(achieved / PEAK, 4),
                          "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo] * (B * T) / 640.0)
                          if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo]) else None,
-                         "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
+                         "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv; direct kernels: r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
                          "algorithmic_flops_per_frame": conv_flops_per_frame(),
                          "note": ("achieved = ALGORITHMIC direct-convolution flops (SURVEY 8d: 27.92 GFLOP/frame, independent of the "
                                   "algorithm) / trunk time; the Winograd kernel executes 2.25x fewer multiplies on 28 of 32 MFMA rows "
