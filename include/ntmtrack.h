@@ -74,8 +74,9 @@ int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, con
 /* The same operator by fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (2.25x fewer multiplies; results equal to
  * ntk_vgg_conv3x3_relu_f32 up to rounding, ~1e-6 relative per layer).  Weights: U = G g G^T for the 16 transform
  * planes, packed lane-major for the MFMA B operand (ntk_vgg_wino_packed_floats(cin, cout) = 16*cin*cout floats).
- * cin a multiple of 16, cout a multiple of 64 (64, 128, 256 or a multiple of 512), H a multiple of 4, W of 28. */
+ * cin a multiple of 16, cout a multiple of 64 (64, 128, 256 or a multiple of 512); H and W multiples of 4. */
 size_t ntk_vgg_wino_packed_floats(int cin, int cout);
+int ntk_vgg_set_wino_variant(int variant);        /* tuning knob for tile grids like 14x14: 1 (default) 2x2x8 tile blocks, 0 14x2; same results */
 int ntk_vgg_pack_weights_wino(const float* w_hwio, float* u_packed, int cin, int cout, void* stream);
 int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                   int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream);

@@ -23,9 +23,12 @@ namespace {
 
 constexpr int WT = 256;            // threads
 constexpr int KC = 16;             // input channels per K iteration
-// tiles per workgroup: 14 wide x 2 tall (28 of the 32 MFMA rows; fits every VGG layer) or 8 x 4 (all 32 rows; layers
-// whose tile grid is a multiple of 8 x 4: conv1_2, conv2_x).  Both patches are 180 pixels (6 x 30 or 10 x 18).
-constexpr int NPX = 180;
+// tiles per workgroup = NSUB sub-blocks of TW x TH tiles, each sub-block a rectangle with its own halo patch:
+//   8 x 4 x 1  all 32 MFMA rows, 180-pixel patch: tile grids that are multiples of 8 x 4 (conv1_2, conv2_x)
+//   4 x 4 x 2  all 32 rows, two 100-pixel patches (consecutive sub-blocks, possibly of different frames): tile grids
+//              that are multiples of 4 x 4 (conv3_x: 28 x 28 tiles)
+//   2 x 2 x 8  all 32 rows, eight 36-pixel patches: any even tile grid (conv4_x: 14 x 14 tiles); 1.6x the staging
+//   14 x 2 x 1 28 of the 32 rows, 180-pixel patch: tile grids that are multiples of 14 x 2 (kept as a tuning choice)
 constexpr int RS = 20;             // LDS row stride (floats) of a 16-channel row: conflict-free ds_read_b128
 constexpr int BNW = 64;            // output channels per workgroup
 
@@ -35,7 +38,8 @@ struct WinoArgs {
     int frames, H, W, Cin, Cout;
     int nCB;            // Cout / 64
     int bxN, byN;       // workgroup blocks per frame: W/(2 TW), H/(2 TH)
-    int NS;             // spatial blocks = frames * byN * bxN
+    int NS;             // workgroups per column block = ceil(NQ / NSUB)
+    int NQ;             // sub-blocks = frames * byN * bxN
 };
 
 // weights: HWIO [3][3][Cin][Cout] -> U_p = G g G^T, packed for the B operand:
@@ -64,11 +68,12 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <bool POOL, int TW, int TH>
+template <bool POOL, int TW, int TH, int NSUB>
 __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
-    constexpr int NTILE = TW * TH, PW = 2 * TW + 2, PH = 2 * TH + 2;
-    static_assert(PW * PH == NPX && NTILE <= 32, "patch must be 180 pixels");
-    __shared__ __attribute__((aligned(16))) float s_raw[NPX * RS];          // 14.4 KB  [pixel][16 ch]
+    constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 2 * TW + 2, PH = 2 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
+    constexpr int NST = (NPX * 4 + WT - 1) / WT;                      // float4 staging slots per thread
+    static_assert(NTILE <= 32 && NPX <= 288, "tile block");
+    __shared__ __attribute__((aligned(16))) float s_raw[NPX * RS];          // 14.4-16 KB  [pixel][16 ch]
     __shared__ __attribute__((aligned(16))) float s_V[16 * 32 * RS];        // 40 KB    [plane][tile][16 ch]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,35 +93,62 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
         sp = slot * per + xcd / a.nCB;
     }
     if (sp >= a.NS) return;
-    const int bx = sp % a.bxN;
-    const int t1 = sp / a.bxN;
-    const int by = t1 % a.byN;
-    const int f = t1 / a.byN;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-    const int y0 = 2 * TH * by - 1, x0 = 2 * TW * bx - 1;        // top-left of the input patch
-
-    // ---- patch staging: 180 pixels x 4 float4 = 720 float4 slots, 3 per thread (the last one partial)
-    const float* src[3];
-    int dst[3];
+    // frame, first output row / column of each sub-block: registers for one or two sub-blocks, a small LDS table
+    // (indexed per lane in the prologue and the epilogue) for eight
+    constexpr bool SBL = NSUB > 2;
+    __shared__ int s_sbf[SBL ? NSUB : 1], s_sby[SBL ? NSUB : 1], s_sbx[SBL ? NSUB : 1];
+    int r_sbf[SBL ? 1 : NSUB], r_sby[SBL ? 1 : NSUB], r_sbx[SBL ? 1 : NSUB];
+    auto sb_decode = [&](int q, int& f_, int& y_, int& x_) {
+        const int sq = sp * NSUB + q;
+        if (sq < a.NQ) {
+            const int bx = sq % a.bxN;
+            const int t1 = sq / a.bxN;
+            f_ = t1 / a.byN; y_ = 2 * TH * (t1 % a.byN); x_ = 2 * TW * bx;
+        } else {
+            f_ = -1; y_ = 0; x_ = 0;                              // ragged tail: nothing to load or store
+        }
+    };
+    if constexpr (SBL) {
+        if (tid < NSUB) sb_decode(tid, s_sbf[tid], s_sby[tid], s_sbx[tid]);
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+        for (int q = 0; q < NSUB; ++q) sb_decode(q, r_sbf[q], r_sby[q], r_sbx[q]);
+    }
+    auto sb_get = [&](int q, int& f_, int& y_, int& x_) {
+        if constexpr (SBL) { f_ = s_sbf[q]; y_ = s_sby[q]; x_ = s_sbx[q]; }
+        else {
+            f_ = r_sbf[0]; y_ = r_sby[0]; x_ = r_sbx[0];
+            if (NSUB == 2 && q == 1) { f_ = r_sbf[NSUB - 1]; y_ = r_sby[NSUB - 1]; x_ = r_sbx[NSUB - 1]; }
+        }
+    };
+
+    // ---- patch staging: NPX pixels x 4 float4 slots, NST per thread (the last one partial)
+    constexpr unsigned NOSRC = 0xffffffffu;            // zero padding (SAME) / slot beyond the patch
+    unsigned src[NST];                                 // float offset into the input (host checks it fits 32 bits)
+    int dst[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
         const int s = tid + k * WT;
         const int px = s >> 2, c4 = s & 3;
         dst[k] = -1;
-        src[k] = nullptr;
+        src[k] = NOSRC;
         if (px < NPX) {
-            const int pr = px / PW, pc = px - pr * PW;
-            const int y = y0 + pr, x = x0 + pc;
+            const int q = px / SPX, lp = px - q * SPX;
+            const int pr = lp / PW, pc = lp - pr * PW;
+            int fq, yq, xq;
+            sb_get(q, fq, yq, xq);
+            const int y = yq - 1 + pr, x = xq - 1 + pc;
             dst[k] = px * RS + c4 * 4;
-            if (y >= 0 && y < H && x >= 0 && x < W) src[k] = a.in + (((size_t)f * H + y) * W + x) * Cin + c4 * 4;
-            else src[k] = nullptr;                     // zero padding (SAME)
+            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) src[k] = (unsigned)((((size_t)fq * H + y) * W + x) * Cin + c4 * 4);
         }
     }
-    f32x4 stage[3];
+    f32x4 stage[NST];
     auto load_patch = [&](int cc) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (dst[k] >= 0 && src[k]) stage[k] = *reinterpret_cast<const f32x4*>(src[k] + cc * KC);
+        for (int k = 0; k < NST; ++k) {
+            if (src[k] != NOSRC) stage[k] = *reinterpret_cast<const f32x4*>(a.in + (size_t)src[k] + cc * KC);
             else stage[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -124,8 +156,9 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     // ---- input-transform role: item = (tile, channel quad, half of the plane rows)
     const int it_tile = tid >> 3, it_c4 = (tid >> 1) & 3, it_h = tid & 1;
     const bool it_on = it_tile < NTILE;
-    const int it_tr = it_tile / TW, it_tc = it_tile - it_tr * TW;
-    const float* rawp = s_raw + ((2 * it_tr + it_h) * PW + 2 * it_tc) * RS + it_c4 * 4;   // rows h .. h+2 of the 4x4 window
+    const int it_q = it_tile / STILE, it_tl = it_tile - it_q * STILE;
+    const int it_tr = it_tl / TW, it_tc = it_tl - it_tr * TW;
+    const float* rawp = s_raw + (it_q * SPX + (2 * it_tr + it_h) * PW + 2 * it_tc) * RS + it_c4 * 4;   // rows h .. h+2 of the 4x4 window
     float* vp = s_V + (8 * it_h * 32 + it_tile) * RS + it_c4 * 4;
 
     // ---- MFMA role
@@ -146,7 +179,7 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int cc = 0; cc < nChunk; ++cc) {
         // (1) patch -> LDS
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < NST; ++k)
             if (dst[k] >= 0) *reinterpret_cast<f32x4*>(s_raw + dst[k]) = stage[k];
         __syncthreads();                       // also: every wave is done reading V of the previous chunk
         if (cc + 1 < nChunk) load_patch(cc + 1);
@@ -248,9 +281,12 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
                 y[0][b] = z[0][b] + z[1][b] + z[2][b];
                 y[1][b] = z[1][b] - z[2][b] - z[3][b];
             }
-            if (m < NTILE) {
-                const int tr = m / TW, tc = m - tr * TW;
-                const int oy = 2 * TH * by + 2 * tr, ox = 2 * TW * bx + 2 * tc;
+            const int mq = m / STILE, ml = m - mq * STILE;
+            int f = -1, yq = 0, xq = 0;
+            if (m < NTILE) sb_get(mq, f, yq, xq);
+            if (m < NTILE && f >= 0) {
+                const int tr = ml / TW, tc = ml - tr * TW;
+                const int oy = yq + 2 * tr, ox = xq + 2 * tc;
                 if constexpr (POOL) {
                     const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
                     a.out[(((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n] = fmaxf(v + bv, 0.f);
@@ -268,6 +304,13 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
 
 }  // namespace
 
+static int g_wino_small = 1;     // 1: 2x2x8 tile blocks where neither 8x4 nor 4x4x2 fits; 0: 14x2 blocks when W % 28 == 0
+extern "C" int ntk_vgg_set_wino_variant(int v) {
+    NTK_REQUIRE(v == 0 || v == 1, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_wino_variant: %d (0 or 1)", v);
+    g_wino_small = v;
+    return NTK_OK;
+}
+
 extern "C" size_t ntk_vgg_wino_packed_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
 extern "C" int ntk_vgg_pack_weights_wino(const float* w_hwio, float* u_packed, int cin, int cout, void* stream) {
@@ -284,34 +327,44 @@ extern "C" int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_pac
     NTK_REQUIRE(in && u_packed && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_wino_f32: null pointer");
     NTK_REQUIRE(ntk_aligned16(in) && ntk_aligned16(u_packed) && ntk_aligned16(out), NTK_ERR_BAD_PTR,
                 "ntk_vgg_conv3x3_relu_wino_f32: 16-byte alignment");
-    NTK_REQUIRE(frames > 0 && ((H >= 4 && (H % 4) == 0 && W >= 28 && (W % 28) == 0) || (H >= 8 && (H % 8) == 0 && (W % 16) == 0)),
-                NTK_ERR_UNSUPPORTED,
-                "ntk_vgg_conv3x3_relu_wino_f32: frames=%d H=%d W=%d (H %% 4 == 0 and W %% 28 == 0, or H %% 8 == 0 and W %% 16 == 0)",
-                frames, H, W);
+    NTK_REQUIRE(frames > 0 && H >= 4 && (H % 4) == 0 && W >= 4 && (W % 4) == 0, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino_f32: frames=%d H=%d W=%d (H, W multiples of 4)", frames, H, W);
     NTK_REQUIRE(cin >= KC && (cin % KC) == 0 && cout >= BNW && (cout % BNW) == 0, NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_wino_f32: cin=%d (multiple of 16) cout=%d (multiple of 64)", cin, cout);
+    NTK_REQUIRE((unsigned long long)frames * H * W * cin < 0xffffffffull, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino_f32: input of %d x %d x %d x %d floats exceeds the 32-bit offset range", frames, H, W, cin);
     WinoArgs a;
     a.in = in; a.U = u_packed; a.bias = bias; a.out = out;
     a.frames = frames; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
-    const bool wide = (W % 16) == 0 && (H % 8) == 0;          // 8 x 4 tile blocks: every MFMA row used
+    // tile-block shape (see the table at the top): 0 = 8x4x1, 1 = 4x4x2, 2 = 14x2x1, 3 = 2x2x8
+    int shape = ((W % 16) == 0 && (H % 8) == 0) ? 0 : (((W % 8) == 0 && (H % 8) == 0) ? 1 : 3);
+    if (shape == 3 && g_wino_small == 0 && (W % 28) == 0) shape = 2;
     a.nCB = cout / BNW;
-    a.bxN = wide ? W / 16 : W / 28;
-    a.byN = wide ? H / 8 : H / 4;
-    const long long NS = (long long)frames * a.byN * a.bxN;
+    a.bxN = shape == 0 ? W / 16 : (shape == 1 ? W / 8 : (shape == 2 ? W / 28 : W / 4));
+    a.byN = shape == 2 || shape == 3 ? H / 4 : H / 8;
+    const long long NQ = (long long)frames * a.byN * a.bxN;
+    const long long NS = shape == 1 ? (NQ + 1) / 2 : (shape == 3 ? (NQ + 7) / 8 : NQ);
     NTK_REQUIRE(NS < (1ll << 30) && (a.nCB <= 8 ? (8 % a.nCB) == 0 : (a.nCB % 8) == 0), NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_wino_f32: cout/64=%d must divide or be a multiple of 8", a.nCB);
     a.NS = (int)NS;
+    a.NQ = (int)NQ;
     long long slots;                                  // workgroup ids = slots * 8
     if (a.nCB >= 8) slots = NS * (a.nCB / 8);
     else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
     const long long grid = slots * 8;
     NTK_REQUIRE(grid < (1ll << 31), NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino_f32: grid too large");
-    if (wide) {
-        if (fuse_pool) conv3x3_wino_kernel<true, 8, 4><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
-        else conv3x3_wino_kernel<false, 8, 4><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+    if (shape == 0) {
+        if (fuse_pool) conv3x3_wino_kernel<true, 8, 4, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_wino_kernel<false, 8, 4, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+    } else if (shape == 1) {
+        if (fuse_pool) conv3x3_wino_kernel<true, 4, 4, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_wino_kernel<false, 4, 4, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+    } else if (shape == 3) {
+        if (fuse_pool) conv3x3_wino_kernel<true, 2, 2, 8><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_wino_kernel<false, 2, 2, 8><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
     } else {
-        if (fuse_pool) conv3x3_wino_kernel<true, 14, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
-        else conv3x3_wino_kernel<false, 14, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        if (fuse_pool) conv3x3_wino_kernel<true, 14, 2, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_wino_kernel<false, 14, 2, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
     }
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_wino_f32");
     return NTK_OK;

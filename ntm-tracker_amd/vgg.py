@@ -60,7 +60,7 @@ def pack_weights(w_hwio):
 def wino_supported(cin, cout, H, W):
     nCB = cout // 64
     return (cin % 16 == 0 and cout % 64 == 0 and (8 % nCB == 0 if nCB <= 8 else nCB % 8 == 0)
-            and ((H % 4 == 0 and W % 28 == 0) or (H % 8 == 0 and W % 16 == 0)))
+            and H % 4 == 0 and W % 4 == 0)
 
 
 def pack_weights_wino(w_hwio):

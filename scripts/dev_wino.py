@@ -6,8 +6,11 @@ sys.path.insert(0, ".")
 from ntmtrack import vgg
 from oracle import ntm_oracle as O
 
+import os
+from ntmtrack import _lib
 dev = torch.device("cuda")
 rng = np.random.default_rng(0)
+_lib.lib().ntk_vgg_set_wino_variant(int(os.environ.get("WINO_VARIANT", "1")))
 
 
 def check(F, H, W, cin, cout, pool):
@@ -30,7 +33,7 @@ def check(F, H, W, cin, cout, pool):
 if len(sys.argv) > 1 and sys.argv[1] == "check":
     bad = 0
     for cfg in [(2, 8, 28, 32, 64, False), (2, 8, 28, 64, 64, True), (1, 28, 28, 128, 128, False), (3, 12, 56, 32, 256, True),
-                (1, 28, 28, 64, 512, False), (2, 8, 16, 32, 64, False), (1, 16, 48, 64, 128, True), (1, 112, 112, 64, 128, False)]:
+                (1, 28, 28, 64, 512, False), (2, 8, 16, 32, 64, False), (1, 16, 48, 64, 128, True), (1, 112, 112, 64, 128, False), (1, 8, 24, 32, 64, False), (3, 56, 56, 128, 256, True), (1, 8, 8, 32, 64, True), (1, 4, 4, 32, 64, False), (2, 12, 20, 32, 128, True)]:
         bad += check(*cfg) > 1e-4
     print("BAD" if bad else "OK")
     sys.exit(1 if bad else 0)

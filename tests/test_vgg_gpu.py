@@ -124,11 +124,16 @@ def test_vgg_trunk_bf16_matches_bf16_oracle(cuda):
     (2, 8, 28, 16, 64, False),      # smallest legal block, one K iteration
     (2, 8, 28, 64, 64, True),       # conv1_2-like: one column block, fused pool
     (1, 28, 28, 128, 128, False),   # two column blocks (4 XCDs each)
-    (3, 12, 56, 32, 256, True),     # four column blocks, two blocks per row, ragged XCD groups
+    (3, 12, 28, 32, 256, True),     # four column blocks, ragged XCD groups (14x2 tile blocks)
     (1, 28, 28, 64, 512, False),    # eight column blocks = one per XCD
     (1, 4, 28, 32, 1024, False),    # sixteen column blocks (two per XCD)
     (2, 8, 16, 32, 64, False),      # 8x4 tile blocks (all 32 MFMA rows): smallest
     (1, 16, 48, 64, 128, True),     # 8x4 tile blocks, several blocks per row, fused pool
+    (1, 8, 24, 32, 64, False),      # 4x4x2 sub-block pairs (tile grid a multiple of 4x4 only), odd sub-block count
+    (3, 56, 56, 128, 256, True),    # conv3-like: sub-block pairs straddling rows and frames, fused pool
+    (1, 4, 4, 32, 64, False),       # 2x2x8 sub-blocks: a single tile block with 7 empty sub-blocks
+    (2, 12, 20, 32, 128, True),     # 2x2x8 sub-blocks, ragged tail, fused pool
+    (1, 28, 28, 32, 512, False),    # conv4-like tile grid (14 x 14) through the 2x2x8 path
 ])
 def test_conv3x3_relu_winograd_matches_oracle(cuda, F, H, W, cin, cout, pool):
     from ntmtrack import vgg
@@ -151,7 +156,7 @@ def test_winograd_rejects_bad_shapes(cuda):
     b = torch.zeros(64, device=cuda)
     u = torch.zeros(16 * 32 * 64, device=cuda)
     with pytest.raises(_lib.NtkError):
-        vgg.conv3x3_relu_wino(torch.zeros((1, 8, 40, 32), device=cuda), u, b, 32, 64)      # W neither a multiple of 28 nor of 16
+        vgg.conv3x3_relu_wino(torch.zeros((1, 8, 30, 32), device=cuda), u, b, 32, 64)      # W not a multiple of 4
     with pytest.raises(_lib.NtkError):
         vgg.conv3x3_relu_wino(torch.zeros((1, 6, 28, 32), device=cuda), u, b, 32, 64)      # H not a multiple of 4
     assert not vgg.wino_supported(3, 64, 224, 224) and not vgg.wino_supported(64, 192, 224, 224)
