@@ -57,10 +57,12 @@ def pack_weights(w_hwio):
     return wp
 
 
-def wino_supported(cin, cout, H, W):
+def wino_supported(cin, cout, H, W, frames=1):
+    """Shapes the fused Winograd kernel takes (otherwise the direct kernel runs): channel multiples, H and W
+    multiples of 4, and an input small enough for its 32-bit element offsets."""
     nCB = cout // 64
-    return (cin % 16 == 0 and cout % 64 == 0 and (8 % nCB == 0 if nCB <= 8 else nCB % 8 == 0)
-            and H % 4 == 0 and W % 4 == 0)
+    return (cin % 16 == 0 and cout % 64 == 0 and nCB >= 1 and (8 % nCB == 0 if nCB <= 8 else nCB % 8 == 0)
+            and H % 4 == 0 and W % 4 == 0 and frames * H * W * cin < 0xffffffff)
 
 
 def pack_weights_wino(w_hwio):
@@ -166,7 +168,7 @@ class VGG16Conv43(object):
         for name, cin, cout, pool in VGG_LAYERS:
             wp, b = self.packed[name]
             last = (name == upto)
-            if name in self.packed_wino and wino_supported(cin, cout, x.shape[1], x.shape[2]):
+            if name in self.packed_wino and wino_supported(cin, cout, x.shape[1], x.shape[2], x.shape[0]):
                 x = conv3x3_relu_wino(x, self.packed_wino[name], b, cin, cout, fuse_pool=(pool and not last),
                                       out=out if last else None)
             else:
