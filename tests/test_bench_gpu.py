@@ -1,0 +1,38 @@
+"""GPU: bench.py contract -- one JSON line with the driver's keys plus roofline / memory_step (tiny workload)."""
+import importlib
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_emits_contract_json(cuda, capsys, monkeypatch):
+    # in-process (this process already owns the GPU: no exec of a second program from here)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                                      "--seq-len", "2", "--no-cpu-baseline"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "memory_step"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["data"] == "synthetic" and out["dtype"] == "f32"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    r = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # frames/s = frames per step / seconds per step
+    assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2
