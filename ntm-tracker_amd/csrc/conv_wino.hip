@@ -302,12 +302,242 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Variant 2: software-pipelined K loop.  8 input channels per iteration; wave w transforms exactly the planes it
+// multiplies (i = w), into its half of a DOUBLE-buffered V, while it multiplies the previous chunk from the other
+// half: the transform's LDS/VALU work sits in the shadow of the wave's own MFMAs instead of in a separate phase.
+// The patch is double-buffered too: ONE workgroup barrier per iteration.  LDS images (bank rules:
+// MI355X_MICROARCH.md): patch = 12 floats per pixel (8 channels + pad); V row = 8 floats with the two 16-byte
+// chunks of tile row m swapped when (m >> 3) & 1 -- conflict-free ds_read_b128 for both the transform's window
+// reads and the MFMA A fragments, conflict-free ds_write_b128 for the transform's stores.
+// Same packed weights, same tile shapes, same epilogue as variant 1.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KC2 = 8, RSR2 = 12, RSV2 = 8;
+__device__ __attribute__((aligned(16))) float g_wino_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <bool POOL, int TW, int TH, int NSUB>
+__global__ __launch_bounds__(WT, 2) void conv3x3_wino2_kernel(WinoArgs a) {
+    constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 2 * TW + 2, PH = 2 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
+    constexpr int NST = (NPX * 2 + WT - 1) / WT;                      // float4 staging slots per thread (2 per pixel)
+    constexpr int RAWSZ = NPX * RSR2, VSZ = 16 * 32 * RSV2;            // (+16 floats of scratch per patch buffer)
+    static_assert(NTILE <= 32 && NPX <= 288, "tile block");
+    __shared__ __attribute__((aligned(16))) float s_raw[2 * (RAWSZ + 16)];  // 2 x 8.6-13.8 KB
+    __shared__ __attribute__((aligned(16))) float s_V[2 * VSZ];             // 2 x 16 KB (32 KB: also the epilogue's Z)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    int cb, sp;
+    if (a.nCB >= 8) {
+        const int kN = a.nCB >> 3;
+        cb = (slot % kN) * 8 + xcd;
+        sp = slot / kN;
+    } else {
+        const int per = 8 / a.nCB;
+        cb = xcd % a.nCB;
+        sp = slot * per + xcd / a.nCB;
+    }
+    if (sp >= a.NS) return;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    __shared__ int s_sbf[NSUB], s_sby[NSUB], s_sbx[NSUB];
+    if (tid < NSUB) {
+        const int sq = sp * NSUB + tid;
+        if (sq < a.NQ) {
+            const int bx = sq % a.bxN;
+            const int t1 = sq / a.bxN;
+            s_sbf[tid] = t1 / a.byN; s_sby[tid] = 2 * TH * (t1 % a.byN); s_sbx[tid] = 2 * TW * bx;
+        } else {
+            s_sbf[tid] = -1; s_sby[tid] = 0; s_sbx[tid] = 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- patch staging: NPX pixels x 2 float4 slots
+    // branch-free: padding pixels and slots beyond the patch read a zero page with stride 0 and, for the latter,
+    // store into a scratch slot behind the patch image
+    const float* src[NST];
+    int sstep[NST], dst[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int s = tid + k * WT;
+        const int px = s >> 1, c4 = s & 1;
+        dst[k] = NPX * RSR2 + (tid & 3) * 4;            // scratch (4 float4 behind each patch buffer)
+        src[k] = g_wino_zero;
+        sstep[k] = 0;
+        if (px < NPX) {
+            const int q = px / SPX, lp = px - q * SPX;
+            const int pr = lp / PW, pc = lp - pr * PW;
+            const int fq = s_sbf[q];
+            const int y = s_sby[q] - 1 + pr, x = s_sbx[q] - 1 + pc;
+            dst[k] = px * RSR2 + c4 * 4;
+            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
+                src[k] = a.in + (((size_t)fq * H + y) * W + x) * Cin + c4 * 4;
+                sstep[k] = KC2;
+            }
+        }
+    }
+    f32x4 stage[NST];
+    auto load_patch = [&](int c8) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) stage[k] = *reinterpret_cast<const f32x4*>(src[k] + c8 * sstep[k]);
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) *reinterpret_cast<f32x4*>(s_raw + buf * (RAWSZ + 16) + dst[k]) = stage[k];
+    };
+
+    // ---- transform role (plane row i = wave): lane -> tile lane >> 1, channel quad lane & 1
+    const int pt_tile = lane >> 1, pt_c4 = lane & 1;
+    const bool pt_on = pt_tile < NTILE;
+    const int pt_q = pt_tile / STILE, pt_tl = pt_tile - pt_q * STILE;
+    const int pt_tr = pt_tl / TW, pt_tc = pt_tl - pt_tr * TW;
+    const int pt_rA = (wave == 0) ? 0 : (wave == 2 ? 2 : 1), pt_rB = (wave == 0) ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float pt_sg = (wave == 1) ? 1.f : -1.f;        // t = d[rA] + sg d[rB]: i0 r0-r2, i1 r1+r2, i2 r2-r1, i3 r1-r3
+    // lanes of tile rows >= NTILE transform window 0 into their own (unused) V rows: no divergence
+    const int pt_ra = pt_on ? (pt_q * SPX + (2 * pt_tr + pt_rA) * PW + 2 * pt_tc) * RSR2 + pt_c4 * 4 : pt_c4 * 4;
+    const int pt_rb = pt_on ? (pt_q * SPX + (2 * pt_tr + pt_rB) * PW + 2 * pt_tc) * RSR2 + pt_c4 * 4 : pt_c4 * 4;
+    const int pt_v = ((4 * wave) * 32 + pt_tile) * RSV2 + ((pt_c4 ^ ((pt_tile >> 3) & 1)) * 4);
+
+    // ---- MFMA role
+    const int mrow = lane & 31, kh = lane >> 5;
+    const int va = ((4 * wave) * 32 + mrow) * RSV2 + ((kh ^ ((mrow >> 3) & 1)) * 4);
+    const int n8 = Cin / KC2;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
+
+    // the transform in two halves: the window reads are requested two planes of MFMAs (~2000 cycles) before the
+    // arithmetic and the stores, so the in-order wave never waits for LDS on its MFMA stream
+    f32x4 tda[4], tdb[4];
+    auto tr_load = [&](int rbuf) {
+        const float* rp = s_raw + rbuf * (RAWSZ + 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tda[c] = *reinterpret_cast<const f32x4*>(rp + pt_ra + c * RSR2);
+            tdb[c] = *reinterpret_cast<const f32x4*>(rp + pt_rb + c * RSR2);
+        }
+    };
+    auto tr_store = [&](int vbuf) {
+        f32x4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = tda[c] + pt_sg * tdb[c];
+        float* o = s_V + vbuf * VSZ + pt_v;
+        *reinterpret_cast<f32x4*>(o) = t[0] - t[2];
+        *reinterpret_cast<f32x4*>(o + 32 * RSV2) = t[1] + t[2];
+        *reinterpret_cast<f32x4*>(o + 2 * 32 * RSV2) = t[2] - t[1];
+        *reinterpret_cast<f32x4*>(o + 3 * 32 * RSV2) = t[1] - t[3];
+    };
+    auto transform = [&](int rbuf, int vbuf) { tr_load(rbuf); tr_store(vbuf); };
+
+    // ---- prologue: patch 0 -> raw[0], transform -> V[0]; patch 1 in flight
+    load_patch(0);
+    store_patch(0);
+    __syncthreads();
+    load_patch(n8 > 1 ? 1 : 0);
+    transform(0, 0);
+    // operand registers ping-pong by plane parity (4 planes per chunk: the parity carries over chunk boundaries),
+    // so a prefetch lands in the registers its MFMAs read -- no copies.  The loop body is branch-free: the last
+    // iteration harmlessly re-requests chunk 0's U, re-stages the last patch and re-transforms it.
+    f32x4 Bq[2][2], Aq[2];                      // [parity][column block], [parity]
+    const unsigned useg = __builtin_amdgcn_readfirstlane((unsigned)(4 * wave)) * 1024u;
+    const float* ubase = a.U + (size_t)cb * (Cin / KC) * 16 * 1024 + useg;                 // wave-uniform (SGPR) part
+    const unsigned ulane = (unsigned)lane * 4u;
+    Bq[0][0] = *reinterpret_cast<const f32x4*>(ubase + ulane);
+    Bq[0][1] = *reinterpret_cast<const f32x4*>(ubase + 256 + ulane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    for (int c8 = 0; c8 < n8; ++c8) {
+        const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;                 // next chunk (wraps on the last iteration)
+        const int cp = (c8 + 2 < n8) ? c8 + 2 : n8 - 1;            // patch to request
+        store_patch((c8 + 1) & 1);
+        __syncthreads();
+        load_patch(cp);
+        const float* uc = ubase + ((size_t)(c8 >> 1) * 16) * 1024 + (c8 & 1) * 512;
+        const float* un = ubase + ((size_t)(cn >> 1) * 16) * 1024 + (cn & 1) * 512;
+        const float* vcur = s_V + (c8 & 1) * VSZ + va;
+        Aq[0] = *reinterpret_cast<const f32x4*>(vcur);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* up = (j < 3) ? uc + (j + 1) * 1024 : un;
+            Bq[(j + 1) & 1][0] = *reinterpret_cast<const f32x4*>(up + ulane);
+            Bq[(j + 1) & 1][1] = *reinterpret_cast<const f32x4*>(up + 256 + ulane);
+            if (j < 3) Aq[(j + 1) & 1] = *reinterpret_cast<const f32x4*>(vcur + (j + 1) * 32 * RSV2);
+            if (j == 0) tr_load((c8 + 1) & 1);          // next chunk's window reads ...
+            if (j == 2) tr_store((c8 + 1) & 1);         // ... become its V two planes of MFMAs later
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[j & 1][q], Bq[j & 1][0][q], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[j & 1][q], Bq[j & 1][1][q], acc[j][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+
+    // ---- epilogue (as variant 1)
+    float* sZ = s_V;
+    const int col = lane & 31;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float z0 = acc[0][nb][r] + acc[1][nb][r] + acc[2][nb][r];
+            const float z1 = acc[1][nb][r] - acc[2][nb][r] - acc[3][nb][r];
+            sZ[((wave * 2 + 0) * 16 + r) * 64 + lane] = z0;
+            sZ[((wave * 2 + 1) * 16 + r) * 64 + lane] = z1;
+        }
+        __syncthreads();
+        const int n = BNW * cb + 32 * nb + col;
+        const float bv = a.bias[n];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
+            float z[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) z[i][b] = sZ[((i * 2 + b) * 16 + r) * 64 + lane];
+            float y[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                y[0][b] = z[0][b] + z[1][b] + z[2][b];
+                y[1][b] = z[1][b] - z[2][b] - z[3][b];
+            }
+            const int mq = m / STILE, ml = m - mq * STILE;
+            const int f = (m < NTILE) ? s_sbf[mq] : -1;
+            if (f >= 0) {
+                const int tr = ml / TW, tc = ml - tr * TW;
+                const int oy = s_sby[mq] + 2 * tr, ox = s_sbx[mq] + 2 * tc;
+                if constexpr (POOL) {
+                    const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+                    a.out[(((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n] = fmaxf(v + bv, 0.f);
+                } else {
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            a.out[(((size_t)f * H + oy + aa) * W + ox + b) * Cout + n] = fmaxf(y[aa][b] + bv, 0.f);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
+static int g_wino_pipe = 1;      // 1 (default): software-pipelined K loop (conv3x3_wino2_kernel); 0: two-phase loop
 static int g_wino_small = 1;     // 1: 2x2x8 tile blocks where neither 8x4 nor 4x4x2 fits; 0: 14x2 blocks when W % 28 == 0
 extern "C" int ntk_vgg_set_wino_variant(int v) {
-    NTK_REQUIRE(v == 0 || v == 1, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_wino_variant: %d (0 or 1)", v);
-    g_wino_small = v;
+    NTK_REQUIRE(v >= 0 && v <= 3, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_wino_variant: %d (bit 0: 2x2x8 tile blocks, bit 1: pipelined K loop)", v);
+    g_wino_small = v & 1;
+    g_wino_pipe = (v >> 1) & 1;
     return NTK_OK;
 }
 
@@ -353,19 +583,21 @@ extern "C" int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_pac
     else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
     const long long grid = slots * 8;
     NTK_REQUIRE(grid < (1ll << 31), NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino_f32: grid too large");
+#define WINO_LAUNCH(POOL_, TW_, TH_, NSUB_)                                                                               \
+    do {                                                                                                                  \
+        if (g_wino_pipe) conv3x3_wino2_kernel<POOL_, TW_, TH_, NSUB_><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a); \
+        else conv3x3_wino_kernel<POOL_, TW_, TH_, NSUB_><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);              \
+    } while (0)
     if (shape == 0) {
-        if (fuse_pool) conv3x3_wino_kernel<true, 8, 4, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
-        else conv3x3_wino_kernel<false, 8, 4, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        if (fuse_pool) WINO_LAUNCH(true, 8, 4, 1); else WINO_LAUNCH(false, 8, 4, 1);
     } else if (shape == 1) {
-        if (fuse_pool) conv3x3_wino_kernel<true, 4, 4, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
-        else conv3x3_wino_kernel<false, 4, 4, 2><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        if (fuse_pool) WINO_LAUNCH(true, 4, 4, 2); else WINO_LAUNCH(false, 4, 4, 2);
     } else if (shape == 3) {
-        if (fuse_pool) conv3x3_wino_kernel<true, 2, 2, 8><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
-        else conv3x3_wino_kernel<false, 2, 2, 8><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        if (fuse_pool) WINO_LAUNCH(true, 2, 2, 8); else WINO_LAUNCH(false, 2, 2, 8);
     } else {
-        if (fuse_pool) conv3x3_wino_kernel<true, 14, 2, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
-        else conv3x3_wino_kernel<false, 14, 2, 1><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);
+        if (fuse_pool) WINO_LAUNCH(true, 14, 2, 1); else WINO_LAUNCH(false, 14, 2, 1);
     }
+#undef WINO_LAUNCH
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_wino_f32");
     return NTK_OK;
 }
