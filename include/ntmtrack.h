@@ -76,7 +76,7 @@ int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, con
  * planes, packed lane-major for the MFMA B operand (ntk_vgg_wino_packed_floats(cin, cout) = 16*cin*cout floats).
  * cin a multiple of 16, cout a multiple of 64 (64, 128, 256 or a multiple of 512); H and W multiples of 4. */
 size_t ntk_vgg_wino_packed_floats(int cin, int cout);
-int ntk_vgg_set_wino_variant(int variant);        /* tuning knob, same results (default 3): bit 0 2x2x8 tile blocks for grids like 14x14 (else 14x2); bit 1 software-pipelined K loop (else two-phase loop) */
+int ntk_vgg_set_wino_variant(int variant);        /* tuning knob for tile grids like 14x14: 1 (default) 2x2x8 tile blocks, 0 14x2; same results */
 int ntk_vgg_pack_weights_wino(const float* w_hwio, float* u_packed, int cin, int cout, void* stream);
 int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                   int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream);

@@ -9,27 +9,27 @@
 // run in the epilogue.  Nothing but the NHWC activations and the pre-transformed weights touches HBM.
 //
 // Work decomposition
-//   workgroup (256 threads = 4 waves): 28 tiles (14 wide x 2 tall = 28 x 4 output pixels) x 64 output channels;
-//     28 of the 32 MFMA rows are used (W/2 is a multiple of 14 for 224/112/56/28).
+//   workgroup (256 threads = 4 waves): 32 tiles (= 32 MFMA rows; tile-block shapes below) x 64 output channels.
 //   wave w owns the four planes p = 4w .. 4w+3 (i = w, j = 0..3): 4 planes x 2 column blocks x 16 = 128
 //     accumulator registers.  A operand (V_p) from LDS, B operand (U_p) straight from global memory in a
 //     lane-major packed layout (each wave reads only its own planes: no reuse inside the workgroup to stage for).
-//   K loop: 16 input channels per iteration: stage the 6 x 30 pixel patch (halo included), transform, 64 MFMAs/wave.
+//   K loop: 8 input channels per iteration, software-pipelined (see the kernel): stage the patch (halo included),
+//     transform, 32 MFMAs per wave.
 //   Cross-wave part of A^T M A goes through LDS once per workgroup.
+//   XCD-aware 1-D grid: an XCD keeps one column block, so its U slice stays in that XCD's L2.
 // Results differ from the direct kernel by rounding only (different summation order, ~1e-6 relative per layer).
 #include "common.h"
 
 namespace {
 
 constexpr int WT = 256;            // threads
-constexpr int KC = 16;             // input channels per K iteration
+constexpr int KC = 16;             // channel granularity of the packed weights / entry-point checks
 // tiles per workgroup = NSUB sub-blocks of TW x TH tiles, each sub-block a rectangle with its own halo patch:
 //   8 x 4 x 1  all 32 MFMA rows, 180-pixel patch: tile grids that are multiples of 8 x 4 (conv1_2, conv2_x)
 //   4 x 4 x 2  all 32 rows, two 100-pixel patches (consecutive sub-blocks, possibly of different frames): tile grids
 //              that are multiples of 4 x 4 (conv3_x: 28 x 28 tiles)
 //   2 x 2 x 8  all 32 rows, eight 36-pixel patches: any even tile grid (conv4_x: 14 x 14 tiles); 1.6x the staging
 //   14 x 2 x 1 28 of the 32 rows, 180-pixel patch: tile grids that are multiples of 14 x 2 (kept as a tuning choice)
-constexpr int RS = 20;             // LDS row stride (floats) of a 16-channel row: conflict-free ds_read_b128
 constexpr int BNW = 64;            // output channels per workgroup
 
 
@@ -42,21 +42,21 @@ struct WinoArgs {
     int NQ;             // sub-blocks = frames * byN * bxN
 };
 
-// weights: HWIO [3][3][Cin][Cout] -> U_p = G g G^T, packed for the B operand:
-// index = ((((cb * nChunk + cc) * 16 + p) * 2 + blk) * 2 + nblk) * 256 + lane * 4 + q
-//   with  c = 16 cc + 8 blk + 4 (lane >> 5) + q,   cout = 64 cb + 32 nblk + (lane & 31)
+// weights: HWIO [3][3][Cin][Cout] -> U_p = G g G^T, packed for the B operand so that ONE wave's fragments of one
+// 8-channel K step are 8 KB contiguous (one scalar base + immediate offsets address all of them):
+// index = ((((cb * n8 + c8) * 4 + w) * 4 + j) * 2 + nblk) * 256 + lane * 4 + q
+//   with  p = 4 w + j,   c = 8 c8 + 4 (lane >> 5) + q,   cout = 64 cb + 32 nblk + (lane & 31)
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout) {
     const size_t total = (size_t)16 * Cin * Cout;
-    const int nChunk = Cin / KC;
+    const int n8 = Cin / 8;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int q = idx & 3, lane = (idx >> 2) & 63;
         size_t r = idx >> 8;
         const int nblk = r & 1; r >>= 1;
-        const int blk = r & 1; r >>= 1;
-        const int p = r & 15; r >>= 4;
-        const int cc = (int)(r % nChunk);
-        const int cb = (int)(r / nChunk);
-        const int c = KC * cc + 8 * blk + 4 * (lane >> 5) + q;
+        const int p = r & 15; r >>= 4;                  // (w, j) = (p >> 2, p & 3): 4 w + j
+        const int c8 = (int)(r % n8);
+        const int cb = (int)(r / n8);
+        const int c = 8 * c8 + 4 * (lane >> 5) + q;
         const int o = BNW * cb + 32 * nblk + (lane & 31);
         const int i = p >> 2, j = p & 3;
         // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -68,255 +68,23 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <bool POOL, int TW, int TH, int NSUB>
-__global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
-    constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 2 * TW + 2, PH = 2 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
-    constexpr int NST = (NPX * 4 + WT - 1) / WT;                      // float4 staging slots per thread
-    static_assert(NTILE <= 32 && NPX <= 288, "tile block");
-    __shared__ __attribute__((aligned(16))) float s_raw[NPX * RS];          // 14.4-16 KB  [pixel][16 ch]
-    __shared__ __attribute__((aligned(16))) float s_V[16 * 32 * RS];        // 40 KB    [plane][tile][16 ch]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // ---- XCD-aware decode: consecutive workgroup ids rotate over the 8 XCDs; an XCD keeps one column block
-    //      (its U slice stays in that XCD's L2) and a contiguous run of spatial blocks
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    int cb, sp;
-    if (a.nCB >= 8) {
-        // column blocks 8k + xcd: slot enumerates (spatial, k)
-        const int kN = a.nCB >> 3;
-        cb = (slot % kN) * 8 + xcd;
-        sp = slot / kN;
-    } else {
-        const int per = 8 / a.nCB;                 // XCDs per column block
-        cb = xcd % a.nCB;
-        sp = slot * per + xcd / a.nCB;
-    }
-    if (sp >= a.NS) return;
-    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-    // frame, first output row / column of each sub-block: registers for one or two sub-blocks, a small LDS table
-    // (indexed per lane in the prologue and the epilogue) for eight
-    constexpr bool SBL = NSUB > 2;
-    __shared__ int s_sbf[SBL ? NSUB : 1], s_sby[SBL ? NSUB : 1], s_sbx[SBL ? NSUB : 1];
-    int r_sbf[SBL ? 1 : NSUB], r_sby[SBL ? 1 : NSUB], r_sbx[SBL ? 1 : NSUB];
-    auto sb_decode = [&](int q, int& f_, int& y_, int& x_) {
-        const int sq = sp * NSUB + q;
-        if (sq < a.NQ) {
-            const int bx = sq % a.bxN;
-            const int t1 = sq / a.bxN;
-            f_ = t1 / a.byN; y_ = 2 * TH * (t1 % a.byN); x_ = 2 * TW * bx;
-        } else {
-            f_ = -1; y_ = 0; x_ = 0;                              // ragged tail: nothing to load or store
-        }
-    };
-    if constexpr (SBL) {
-        if (tid < NSUB) sb_decode(tid, s_sbf[tid], s_sby[tid], s_sbx[tid]);
-        __syncthreads();
-    } else {
-#pragma unroll
-        for (int q = 0; q < NSUB; ++q) sb_decode(q, r_sbf[q], r_sby[q], r_sbx[q]);
-    }
-    auto sb_get = [&](int q, int& f_, int& y_, int& x_) {
-        if constexpr (SBL) { f_ = s_sbf[q]; y_ = s_sby[q]; x_ = s_sbx[q]; }
-        else {
-            f_ = r_sbf[0]; y_ = r_sby[0]; x_ = r_sbx[0];
-            if (NSUB == 2 && q == 1) { f_ = r_sbf[NSUB - 1]; y_ = r_sby[NSUB - 1]; x_ = r_sbx[NSUB - 1]; }
-        }
-    };
-
-    // ---- patch staging: NPX pixels x 4 float4 slots, NST per thread (the last one partial)
-    constexpr unsigned NOSRC = 0xffffffffu;            // zero padding (SAME) / slot beyond the patch
-    unsigned src[NST];                                 // float offset into the input (host checks it fits 32 bits)
-    int dst[NST];
-#pragma unroll
-    for (int k = 0; k < NST; ++k) {
-        const int s = tid + k * WT;
-        const int px = s >> 2, c4 = s & 3;
-        dst[k] = -1;
-        src[k] = NOSRC;
-        if (px < NPX) {
-            const int q = px / SPX, lp = px - q * SPX;
-            const int pr = lp / PW, pc = lp - pr * PW;
-            int fq, yq, xq;
-            sb_get(q, fq, yq, xq);
-            const int y = yq - 1 + pr, x = xq - 1 + pc;
-            dst[k] = px * RS + c4 * 4;
-            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) src[k] = (unsigned)((((size_t)fq * H + y) * W + x) * Cin + c4 * 4);
-        }
-    }
-    f32x4 stage[NST];
-    auto load_patch = [&](int cc) {
-#pragma unroll
-        for (int k = 0; k < NST; ++k) {
-            if (src[k] != NOSRC) stage[k] = *reinterpret_cast<const f32x4*>(a.in + (size_t)src[k] + cc * KC);
-            else stage[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-
-    // ---- input-transform role: item = (tile, channel quad, half of the plane rows)
-    const int it_tile = tid >> 3, it_c4 = (tid >> 1) & 3, it_h = tid & 1;
-    const bool it_on = it_tile < NTILE;
-    const int it_q = it_tile / STILE, it_tl = it_tile - it_q * STILE;
-    const int it_tr = it_tl / TW, it_tc = it_tl - it_tr * TW;
-    const float* rawp = s_raw + (it_q * SPX + (2 * it_tr + it_h) * PW + 2 * it_tc) * RS + it_c4 * 4;   // rows h .. h+2 of the 4x4 window
-    float* vp = s_V + (8 * it_h * 32 + it_tile) * RS + it_c4 * 4;
-
-    // ---- MFMA role
-    const int mrow = lane & 31, kh = lane >> 5;
-    const float* va = s_V + ((4 * wave) * 32 + mrow) * RS + 4 * kh;
-    const int nChunk = Cin / KC;
-    const float* ub = a.U + ((size_t)cb * nChunk * 16 + 4 * wave) * 1024 + lane * 4;      // + cc*16*1024 + j*1024 + blk*512 + nblk*256
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
-
-    load_patch(0);
-    for (int cc = 0; cc < nChunk; ++cc) {
-        // (1) patch -> LDS
-#pragma unroll
-        for (int k = 0; k < NST; ++k)
-            if (dst[k] >= 0) *reinterpret_cast<f32x4*>(s_raw + dst[k]) = stage[k];
-        __syncthreads();                       // also: every wave is done reading V of the previous chunk
-        if (cc + 1 < nChunk) load_patch(cc + 1);
-        // B operand of plane j = 0 (prefetch before the transform)
-        const float* uc = ub + (size_t)cc * 16 * 1024;
-        f32x4 bq[2][2];                        // [blk][nblk]
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) bq[blk][nb] = *reinterpret_cast<const f32x4*>(uc + blk * 512 + nb * 256);
-
-        // (2) input transform: V = B^T d B for plane rows i = 2h, 2h+1 (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
-        if (it_on) {
-            f32x4 d[3][4];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[r][c] = *reinterpret_cast<const f32x4*>(rawp + (r * PW + c) * RS);
-            // half 0 holds window rows 0,1,2 -> i=0: r0-r2, i=1: r1+r2 ; half 1 holds rows 1,2,3 -> i=2: r2-r1, i=3: r1-r3
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                f32x4 t[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (it_h == 0) t[c] = (ii == 0) ? (d[0][c] - d[2][c]) : (d[1][c] + d[2][c]);
-                    else t[c] = (ii == 0) ? (d[1][c] - d[0][c]) : (d[0][c] - d[2][c]);
-                }
-                float* o = vp + (4 * ii) * 32 * RS;
-                *reinterpret_cast<f32x4*>(o) = t[0] - t[2];
-                *reinterpret_cast<f32x4*>(o + 32 * RS) = t[1] + t[2];
-                *reinterpret_cast<f32x4*>(o + 2 * 32 * RS) = t[2] - t[1];
-                *reinterpret_cast<f32x4*>(o + 3 * 32 * RS) = t[1] - t[3];
-            }
-        }
-        __syncthreads();
-
-        // (3) 4 planes x 2 column blocks x 8 k-steps of v_mfma_f32_32x32x2_f32
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 bn[2][2];
-            if (j < 3) {
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        bn[blk][nb] = *reinterpret_cast<const f32x4*>(uc + (j + 1) * 1024 + blk * 512 + nb * 256);
-            }
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(va + j * 32 * RS);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(va + j * 32 * RS + 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bq[0][0][q], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bq[0][1][q], acc[j][1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bq[1][0][q], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bq[1][1][q], acc[j][1], 0, 0, 0);
-            }
-            if (j < 3) {
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) bq[blk][nb] = bn[blk][nb];
-            }
-        }
-    }
-
-    // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]].  Row part (over j) inside the wave, column part
-    //      (over i = wave) through LDS: Z[i][b][r][lane], one column block at a time (32 KB, reuses s_V).
-    float* sZ = s_V;
-    const int col = lane & 31;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float z0 = acc[0][nb][r] + acc[1][nb][r] + acc[2][nb][r];
-            const float z1 = acc[1][nb][r] - acc[2][nb][r] - acc[3][nb][r];
-            sZ[((wave * 2 + 0) * 16 + r) * 64 + lane] = z0;
-            sZ[((wave * 2 + 1) * 16 + r) * 64 + lane] = z1;
-        }
-        __syncthreads();
-        const int n = BNW * cb + 32 * nb + col;
-        const float bv = a.bias[n];
-        // wave w finishes accumulator rows r = 4w .. 4w+3 for all four pixels of the tile
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * wave + rr;
-            const int m = 4 * kh + (r & 3) + 8 * (r >> 2);         // tile index of this accumulator row
-            float z[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) z[i][b] = sZ[((i * 2 + b) * 16 + r) * 64 + lane];
-            float y[2][2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                y[0][b] = z[0][b] + z[1][b] + z[2][b];
-                y[1][b] = z[1][b] - z[2][b] - z[3][b];
-            }
-            const int mq = m / STILE, ml = m - mq * STILE;
-            int f = -1, yq = 0, xq = 0;
-            if (m < NTILE) sb_get(mq, f, yq, xq);
-            if (m < NTILE && f >= 0) {
-                const int tr = ml / TW, tc = ml - tr * TW;
-                const int oy = yq + 2 * tr, ox = xq + 2 * tc;
-                if constexpr (POOL) {
-                    const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
-                    a.out[(((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n] = fmaxf(v + bv, 0.f);
-                } else {
-#pragma unroll
-                    for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            a.out[(((size_t)f * H + oy + aa) * W + ox + b) * Cout + n] = fmaxf(y[aa][b] + bv, 0.f);
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// Variant 2: software-pipelined K loop.  8 input channels per iteration; wave w transforms exactly the planes it
+// Software-pipelined K loop.  8 input channels per iteration; wave w transforms exactly the planes it
 // multiplies (i = w), into its half of a DOUBLE-buffered V, while it multiplies the previous chunk from the other
 // half: the transform's LDS/VALU work sits in the shadow of the wave's own MFMAs instead of in a separate phase.
 // The patch is double-buffered too: ONE workgroup barrier per iteration.  LDS images (bank rules:
 // MI355X_MICROARCH.md): patch = 12 floats per pixel (8 channels + pad); V row = 8 floats with the two 16-byte
 // chunks of tile row m swapped when (m >> 3) & 1 -- conflict-free ds_read_b128 for both the transform's window
 // reads and the MFMA A fragments, conflict-free ds_write_b128 for the transform's stores.
-// Same packed weights, same tile shapes, same epilogue as variant 1.
+// On this pipe every VALU / address instruction in the loop costs MFMA issue time (fp32 MFMA and VALU do not
+// co-issue), so the loop is branch-free, copy-free (ping-pong operand registers) and addresses U through one
+// scalar base per iteration + immediates.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KC2 = 8, RSR2 = 12, RSV2 = 8;
-__device__ __attribute__((aligned(16))) float g_wino_zero[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float g_wino_zero[1024] = {0.f};     // padding pixels read zeros here; pointers advance with K (Cin <= 1024)
 
 template <bool POOL, int TW, int TH, int NSUB>
-__global__ __launch_bounds__(WT, 2) void conv3x3_wino2_kernel(WinoArgs a) {
+__global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 2 * TW + 2, PH = 2 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
     constexpr int NST = (NPX * 2 + WT - 1) / WT;                      // float4 staging slots per thread (2 per pixel)
     constexpr int RAWSZ = NPX * RSR2, VSZ = 16 * 32 * RSV2;            // (+16 floats of scratch per patch buffer)
@@ -354,35 +122,35 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino2_kernel(WinoArgs a) {
     // ---- patch staging: NPX pixels x 2 float4 slots
     // branch-free: padding pixels and slots beyond the patch read a zero page with stride 0 and, for the latter,
     // store into a scratch slot behind the patch image
-    const float* src[NST];
-    int sstep[NST], dst[NST];
+    const float* src[NST];                             // running pointers: + 8 floats per K step
+    int dst[NST];                                      // in float4 units (so the stores are ds_write_b128)
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
         const int s = tid + k * WT;
         const int px = s >> 1, c4 = s & 1;
-        dst[k] = NPX * RSR2 + (tid & 3) * 4;            // scratch (4 float4 behind each patch buffer)
+        dst[k] = (NPX * RSR2) / 4 + (tid & 3);          // scratch (4 float4 behind each patch buffer)
         src[k] = g_wino_zero;
-        sstep[k] = 0;
         if (px < NPX) {
             const int q = px / SPX, lp = px - q * SPX;
             const int pr = lp / PW, pc = lp - pr * PW;
             const int fq = s_sbf[q];
             const int y = s_sby[q] - 1 + pr, x = s_sbx[q] - 1 + pc;
-            dst[k] = px * RSR2 + c4 * 4;
-            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
-                src[k] = a.in + (((size_t)fq * H + y) * W + x) * Cin + c4 * 4;
-                sstep[k] = KC2;
-            }
+            dst[k] = px * (RSR2 / 4) + c4;
+            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) src[k] = a.in + (((size_t)fq * H + y) * W + x) * Cin + c4 * 4;
         }
     }
     f32x4 stage[NST];
-    auto load_patch = [&](int c8) {
+    auto load_patch = [&](int step) {                  // request the patch the pointers are at, then advance them
 #pragma unroll
-        for (int k = 0; k < NST; ++k) stage[k] = *reinterpret_cast<const f32x4*>(src[k] + c8 * sstep[k]);
+        for (int k = 0; k < NST; ++k) {
+            stage[k] = *reinterpret_cast<const f32x4*>(src[k]);
+            src[k] += step;
+        }
     };
     auto store_patch = [&](int buf) {
+        f32x4* rb = reinterpret_cast<f32x4*>(s_raw) + buf * ((RAWSZ + 16) / 4);
 #pragma unroll
-        for (int k = 0; k < NST; ++k) *reinterpret_cast<f32x4*>(s_raw + buf * (RAWSZ + 16) + dst[k]) = stage[k];
+        for (int k = 0; k < NST; ++k) rb[dst[k]] = stage[k];
     };
 
     // ---- transform role (plane row i = wave): lane -> tile lane >> 1, channel quad lane & 1
@@ -434,17 +202,18 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino2_kernel(WinoArgs a) {
     auto transform = [&](int rbuf, int vbuf) { tr_load(rbuf); tr_store(vbuf); };
 
     // ---- prologue: patch 0 -> raw[0], transform -> V[0]; patch 1 in flight
-    load_patch(0);
+    load_patch(n8 > 1 ? KC2 : 0);                      // patch 0; pointers now at patch min(1, n8 - 1)
     store_patch(0);
     __syncthreads();
-    load_patch(n8 > 1 ? 1 : 0);
+    load_patch(n8 > 2 ? KC2 : 0);                      // patch min(1, n8 - 1); pointers at min(2, n8 - 1)
     transform(0, 0);
     // operand registers ping-pong by plane parity (4 planes per chunk: the parity carries over chunk boundaries),
     // so a prefetch lands in the registers its MFMAs read -- no copies.  The loop body is branch-free: the last
     // iteration harmlessly re-requests chunk 0's U, re-stages the last patch and re-transforms it.
     f32x4 Bq[2][2], Aq[2];                      // [parity][column block], [parity]
-    const unsigned useg = __builtin_amdgcn_readfirstlane((unsigned)(4 * wave)) * 1024u;
-    const float* ubase = a.U + (size_t)cb * (Cin / KC) * 16 * 1024 + useg;                 // wave-uniform (SGPR) part
+    const unsigned uw = __builtin_amdgcn_readfirstlane((unsigned)wave);
+    // wave-uniform base of this wave's 8 KB of fragments for K step c8: ubase + c8 * 8192 floats
+    const float* ubase = a.U + ((size_t)cb * n8 * 4 + uw) * 2048;
     const unsigned ulane = (unsigned)lane * 4u;
     Bq[0][0] = *reinterpret_cast<const f32x4*>(ubase + ulane);
     Bq[0][1] = *reinterpret_cast<const f32x4*>(ubase + 256 + ulane);
@@ -452,17 +221,16 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino2_kernel(WinoArgs a) {
 
     for (int c8 = 0; c8 < n8; ++c8) {
         const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;                 // next chunk (wraps on the last iteration)
-        const int cp = (c8 + 2 < n8) ? c8 + 2 : n8 - 1;            // patch to request
         store_patch((c8 + 1) & 1);
         __syncthreads();
-        load_patch(cp);
-        const float* uc = ubase + ((size_t)(c8 >> 1) * 16) * 1024 + (c8 & 1) * 512;
-        const float* un = ubase + ((size_t)(cn >> 1) * 16) * 1024 + (cn & 1) * 512;
+        load_patch(c8 + 3 < n8 ? KC2 : 0);                         // requests patch min(c8 + 2, n8 - 1)
+        const float* uc = ubase + (size_t)c8 * 8192;
+        const float* un = ubase + (size_t)cn * 8192;
         const float* vcur = s_V + (c8 & 1) * VSZ + va;
         Aq[0] = *reinterpret_cast<const f32x4*>(vcur);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float* up = (j < 3) ? uc + (j + 1) * 1024 : un;
+            const float* up = (j < 3) ? uc + (j + 1) * 512 : un;
             Bq[(j + 1) & 1][0] = *reinterpret_cast<const f32x4*>(up + ulane);
             Bq[(j + 1) & 1][1] = *reinterpret_cast<const f32x4*>(up + 256 + ulane);
             if (j < 3) Aq[(j + 1) & 1] = *reinterpret_cast<const f32x4*>(vcur + (j + 1) * 32 * RSV2);
@@ -532,12 +300,10 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino2_kernel(WinoArgs a) {
 
 }  // namespace
 
-static int g_wino_pipe = 1;      // 1 (default): software-pipelined K loop (conv3x3_wino2_kernel); 0: two-phase loop
 static int g_wino_small = 1;     // 1: 2x2x8 tile blocks where neither 8x4 nor 4x4x2 fits; 0: 14x2 blocks when W % 28 == 0
 extern "C" int ntk_vgg_set_wino_variant(int v) {
-    NTK_REQUIRE(v >= 0 && v <= 3, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_wino_variant: %d (bit 0: 2x2x8 tile blocks, bit 1: pipelined K loop)", v);
-    g_wino_small = v & 1;
-    g_wino_pipe = (v >> 1) & 1;
+    NTK_REQUIRE(v == 0 || v == 1, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_wino_variant: %d (0 or 1)", v);
+    g_wino_small = v;
     return NTK_OK;
 }
 
@@ -583,11 +349,7 @@ extern "C" int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_pac
     else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
     const long long grid = slots * 8;
     NTK_REQUIRE(grid < (1ll << 31), NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino_f32: grid too large");
-#define WINO_LAUNCH(POOL_, TW_, TH_, NSUB_)                                                                               \
-    do {                                                                                                                  \
-        if (g_wino_pipe) conv3x3_wino2_kernel<POOL_, TW_, TH_, NSUB_><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a); \
-        else conv3x3_wino_kernel<POOL_, TW_, TH_, NSUB_><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a);              \
-    } while (0)
+#define WINO_LAUNCH(POOL_, TW_, TH_, NSUB_) conv3x3_wino_kernel<POOL_, TW_, TH_, NSUB_><<<(unsigned)grid, WT, 0, (hipStream_t)stream>>>(a)
     if (shape == 0) {
         if (fuse_pool) WINO_LAUNCH(true, 8, 4, 1); else WINO_LAUNCH(false, 8, 4, 1);
     } else if (shape == 1) {
