@@ -247,36 +247,43 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
 
-    // ---- epilogue (as variant 1)
-    float* sZ = s_V;
+    // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]].  Row part (over j) inside the wave, column part (over
+    //      i = wave) through LDS, one column block at a time: Z[i][b][r / 4][lane][r % 4] (32 KB = s_V), so both the
+    //      stores and the loads are ds_*_b128 (wave w finishes the accumulator rows r = 4w .. 4w+3).
+    f32x4* sZ4 = reinterpret_cast<f32x4*>(s_V);
     const int col = lane & 31;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float z0 = acc[0][nb][r] + acc[1][nb][r] + acc[2][nb][r];
-            const float z1 = acc[1][nb][r] - acc[2][nb][r] - acc[3][nb][r];
-            sZ[((wave * 2 + 0) * 16 + r) * 64 + lane] = z0;
-            sZ[((wave * 2 + 1) * 16 + r) * 64 + lane] = z1;
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 z0, z1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rq + e;
+                z0[e] = acc[0][nb][r] + acc[1][nb][r] + acc[2][nb][r];
+                z1[e] = acc[1][nb][r] - acc[2][nb][r] - acc[3][nb][r];
+            }
+            sZ4[((wave * 2 + 0) * 4 + rq) * 64 + lane] = z0;
+            sZ4[((wave * 2 + 1) * 4 + rq) * 64 + lane] = z1;
         }
         __syncthreads();
         const int n = BNW * cb + 32 * nb + col;
         const float bv = a.bias[n];
+        f32x4 zz[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) zz[i][b] = sZ4[((i * 2 + b) * 4 + wave) * 64 + lane];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = 4 * wave + rr;
             const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
-            float z[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) z[i][b] = sZ[((i * 2 + b) * 16 + r) * 64 + lane];
             float y[2][2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                y[0][b] = z[0][b] + z[1][b] + z[2][b];
-                y[1][b] = z[1][b] - z[2][b] - z[3][b];
+                y[0][b] = zz[0][b][rr] + zz[1][b][rr] + zz[2][b][rr];
+                y[1][b] = zz[1][b][rr] - zz[2][b][rr] - zz[3][b][rr];
             }
             const int mq = m / STILE, ml = m - mq * STILE;
             const int f = (m < NTILE) ? s_sbf[mq] : -1;
