@@ -165,13 +165,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; NTK_DIST_BACKEND=gloo (rehearsal on a box with fewer GPUs than ranks) lets ranks share a device
+    backend = os.environ.get("NTK_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ntmtrack import tracker
     from ntmtrack.vgg import conv_flops_per_frame
