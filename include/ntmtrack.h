@@ -86,12 +86,8 @@ int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_packed, const 
  * un-fused form with identical results.  H, W even; C a multiple of 4. */
 int ntk_maxpool2x2(const float* in, float* out, int frames, int H, int W, int C, void* stream);
 
-/* Tuning knob: 0 two LDS buffers / 2 workgroups per CU, 1 = 0 + static wave
- * priority, 2 one LDS buffer / 3 workgroups per CU, 3 = 2 at 4 workgroups per
- * CU (spills), 4 (default) LDS-DMA staging, swizzled un-padded LDS image, 4
- * workgroups per CU, 5 = 4 with two 16-deep sub-tile buffers, 6 = 4 with two
- * full-tile buffers at 2 workgroups per CU.  All variants compute bit-identical
- * results; measured rates are in DESIGN.md. */
+/* Tuning knob of the direct kernel: 4 (default) LDS-DMA staging, swizzled un-padded LDS image, 4 workgroups per CU;
+ * 2 VGPR staging, one padded LDS buffer, 3 workgroups per CU.  Bit-identical results; rates in DESIGN.md. */
 int ntk_vgg_set_conv_variant(int variant);
 
 /* ------------------------------------------------------------------------

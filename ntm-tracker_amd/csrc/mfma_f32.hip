@@ -12,12 +12,12 @@
 // per thread: the loop is matrix-pipe bound by construction.  Measured on
 // MI355X (profiles/): co-resident waves of one SIMD run in lockstep
 // and stall at their barriers together, so occupancy decides the pipe's duty
-// cycle -- the shipped conv variant (2) keeps ONE LDS buffer (two barriers per
-// K-tile, 38 KB) so that 3 workgroups fit a CU: 126-128 TFLOP/s per layer vs
-// 116-118 with two LDS buffers at 2 workgroups/CU (variant 0); static wave
-// priority (1) and 4 workgroups/CU at 128 VGPRs (3, spills) both lose.
-// Variant 4 (shipped): LDS-DMA staging (global_load_lds_dwordx4) frees the 32
-// staging VGPRs -> 128 VGPRs, 32 KB LDS, FOUR workgroups per CU: 132-133 TFLOP/s.
+// cycle -- the VGPR-staged kernel (variant 2) keeps ONE LDS buffer (two barriers per
+// K-tile, 38 KB) so that 3 workgroups fit a CU: 126-128 TFLOP/s per layer (two LDS buffers at 2 workgroups/CU,
+// static wave priority, 4 workgroups/CU with spills were measured slower and removed).
+// Variant 4 (default of the direct path): LDS-DMA staging (global_load_lds_dwordx4) frees the 32 staging VGPRs ->
+// 128 VGPRs, 32 KB LDS, FOUR workgroups per CU: 132-133 TFLOP/s.  The default trunk is the Winograd kernel
+// (conv_wino.hip); this file serves algo="direct", tiny-Cin / odd shapes and the plain GEMMs around the recurrence.
 #include "common.h"
 #include "conv_common.h"
 
@@ -89,6 +89,7 @@ __device__ __forceinline__ void gemm_pipeline_sb(LA& la, LB& lb, int nk, float* 
     }
 }
 
+// two LDS buffers (used by the plain GEMM kernels below: their tiles are small and they run at 2 workgroups/CU)
 template <int BN, class LA, class LB>
 __device__ __forceinline__ void gemm_pipeline(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[2][BN / 64]) {
     constexpr int NB = BN / 32;
@@ -139,18 +140,12 @@ __device__ __forceinline__ void gemm_pipeline(LA& la, LB& lb, int nk, float* lds
 // pixel patches, patch-major over (frame, py, px); inside a patch
 // q = m & 15 -> window (q>>3, (q>>2)&1), pixel-in-window ((q>>1)&1, q&1).
 // ---------------------------------------------------------------------------
-template <int BN, bool SMALLC, bool POOL, int VAR, bool OUTBF16 = false>
-__global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv3x3_relu_kernel(
+template <int BN, bool SMALLC, bool POOL, bool OUTBF16 = false>
+__global__ __launch_bounds__(256, 3) void conv3x3_relu_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
     constexpr int TN = BN / 64;
-    __shared__ __attribute__((aligned(16))) float lds[(VAR >= 2 ? 1 : 2) * (BM + BN) * LDT];
-    if constexpr (VAR == 1) {
-        // co-resident waves of one SIMD run the same program in lockstep and stall together at their
-        // barriers; give the wave in the even hardware slot static priority so the two desynchronise
-        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID[3:0] = wave slot
-        if ((hwid & 1u) == 0u) __builtin_amdgcn_s_setprio(1);
-    }
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDT];
     __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
 
     const int tid = threadIdx.x;
@@ -221,8 +216,7 @@ __global__ __launch_bounds__(256, (VAR == 3 ? 4 : (VAR == 2 ? 3 : 2))) void conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    if constexpr (VAR >= 2) gemm_pipeline_sb<BN>(la, lb, Kp / BK, lds, acc);
-    else gemm_pipeline<BN>(la, lb, Kp / BK, lds, acc);
+    gemm_pipeline_sb<BN>(la, lb, Kp / BK, lds, acc);
 
     // epilogue: bias + ReLU (+ 2x2 max over the 4 consecutive rows of a window)
     const int lane = tid & 63, wave = tid >> 6;
@@ -304,13 +298,13 @@ __device__ __forceinline__ void lds_dma16(const float* src, float* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, bool POOL, bool DB = false>
-__global__ __launch_bounds__(256, (DB ? 2 : 4)) void conv3x3_relu_dma_kernel(
+template <int BN, bool POOL>
+__global__ __launch_bounds__(256, 4) void conv3x3_relu_dma_kernel(
     const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
     constexpr int TN = BN / 64, NBI = BN / 32;      // B DMA instructions per wave
     constexpr int TILE = (BM + BN) * BK;
-    __shared__ __attribute__((aligned(1024))) float lds[(DB ? 2 : 1) * TILE];
+    __shared__ __attribute__((aligned(1024))) float lds[TILE];
     __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
 
     const int tid = threadIdx.x;
@@ -370,163 +364,12 @@ __global__ __launch_bounds__(256, (DB ? 2 : 4)) void conv3x3_relu_dma_kernel(
 #pragma unroll
         for (int jj = 0; jj < NBI; ++jj) lds_dma16(bsrc[jj] + kt * BK, Bd + (wave * NBI + jj) * 8 * BK);
     };
-    if constexpr (!DB) {
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt > 0) __syncthreads();                   // every wave has finished reading the previous tile
-            issue(kt, As, Bs);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                               // all four waves' DMA has landed
-            mma_ktile_swz<BN>(As, Bs, acc, wm, wn, lane);
-        }
-    } else {
-        issue(0, As, Bs);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) __syncthreads();                   // every wave has finished reading the previous tile
+        issue(kt, As, Bs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            float* Ac = lds + (kt & 1) * TILE;
-            float* An = lds + ((kt + 1) & 1) * TILE;
-            if (kt + 1 < nk) issue(kt + 1, An, An + BM * BK);
-            mma_ktile_swz<BN>(Ac, Ac + BM * BK, acc, wm, wn, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-
-    const int kh = lane >> 5, col = lane & 31;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn * (BN / 2) + tn * 32 + col;
-        const float bv = bias[n];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int mbase = wm * 64 + tm * 32 + 4 * kh;
-            if constexpr (!POOL) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pix = s_pix[mbase + (r & 3) + 8 * (r >> 2)];
-                    if (pix >= 0) out[(size_t)pix * Cout + n] = fmaxf(acc[tm][tn][r] + bv, 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int pp = s_ppix[mbase + 8 * g];
-                    const float v = fmaxf(fmaxf(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1]),
-                                          fmaxf(acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
-                    if (pp >= 0) out[(size_t)pp * Cout + n] = fmaxf(v + bv, 0.f);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Variant 5: as variant 4, but the K-tile is split into two 16-deep sub-tiles held in TWO LDS buffers (still
-// 32 KB): the DMA of sub-tile s+1 is in flight while sub-tile s is multiplied, so no DMA latency is exposed and
-// there is ONE barrier per 32 MFMAs instead of two per 64 plus an exposed wait.  Rows are 64 B (4 chunks of
-// 16 B); chunk c of row r sits in slot c ^ ((r >> 2) & 3) (conflict-free ds_read_b128: 4 rows per 256-B bank
-// window x 4 slots); one DMA wave-instruction fills 16 rows.
-// ---------------------------------------------------------------------------
-constexpr int BKS = 16;
-
-template <int BN>
-__device__ __forceinline__ void mma_subtile_swz(const float* __restrict__ As, const float* __restrict__ Bs,
-                                                f32x16 (&acc)[2][BN / 64], int wm, int wn, int lane) {
-    constexpr int TN = BN / 64;
-    const int i = lane & 31, kh = lane >> 5, f = (i >> 2) & 3;
-    const float* ap = As + (wm * 64 + i) * BKS;
-    const float* bp = Bs + (wn * (BN / 2) + i) * BKS;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int slot = ((2 * q + kh) ^ f) * 4;
-        f32x4 a[2], b[TN];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(ap + tm * 32 * BKS + slot);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(bp + tn * 32 * BKS + slot);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
-    }
-}
-
-template <int BN, bool POOL>
-__global__ __launch_bounds__(256, 4) void conv3x3_relu_dma2_kernel(
-    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ out, int npatch, int H, int W, int Cin, int Cout, int Kp) {
-    constexpr int TN = BN / 64, NBI = BN / 64;      // B DMA instructions per wave and sub-tile
-    constexpr int SUB = (BM + BN) * BKS;            // floats per sub-tile buffer
-    __shared__ __attribute__((aligned(1024))) float lds[2 * SUB];
-    __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
-
-    const int tid = threadIdx.x;
-    const int ctiles = Cout / BN;
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int rt = (li / ctiles) * 8 + xcd;
-    const int m0 = rt * BM;
-    const int n0 = (li % ctiles) * BN;
-    if (m0 >= npatch * 16) return;
-    if (tid < BM) {
-        ConvRowInfo ri = conv_row_info(m0 + tid, npatch, H, W);
-        s_pix[tid] = ri.pix; s_yx[tid] = ri.yx; s_ppix[tid] = ri.ppix;
-    }
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    // DMA roles: instruction jj of this wave fills rows (wave*2 + jj)*16 .. +15; lane -> (row = lane>>2, slot = lane&3)
-    const int lr = lane >> 2, slot = lane & 3;
-    const int schunk = (slot ^ ((lr >> 2) & 3)) * 4;        // source chunk (floats) of this lane's slot
-    int rpix[2], ry[2], rx[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int r = (wave * 2 + jj) * 16 + lr;
-        rpix[jj] = s_pix[r];
-        const int yx = s_yx[r];
-        ry[jj] = yx >> 16; rx[jj] = yx & 0xffff;
-    }
-    const float* bsrc[NBI];
-#pragma unroll
-    for (int jj = 0; jj < NBI; ++jj) bsrc[jj] = wp + (size_t)(n0 + (wave * NBI + jj) * 16 + lr) * Kp + schunk;
-
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    auto issue = [&](int st) {                              // DMA sub-tile st into buffer st & 1
-        float* As = lds + (st & 1) * SUB;
-        float* Bs = As + BM * BKS;
-        const int kt = st >> 1, half = st & 1;
-        const int chunk = kt / 9, tap = kt - chunk * 9;
-        const int c0 = chunk * BK + half * BKS;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int yy = ry[jj] + dy, xx = rx[jj] + dx;
-            const bool ok = rpix[jj] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const float* src = ok ? in + (size_t)(rpix[jj] + dy * W + dx) * Cin + c0 + schunk : g_zero_page + slot * 4;
-            lds_dma16(src, As + (wave * 2 + jj) * 16 * BKS);
-        }
-#pragma unroll
-        for (int jj = 0; jj < NBI; ++jj) lds_dma16(bsrc[jj] + kt * BK + half * BKS, Bs + (wave * NBI + jj) * 16 * BKS);
-    };
-
-    const int nst = 2 * (Kp / BK);
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        if (st + 1 < nst) issue(st + 1);                    // lands in the other buffer while this one is multiplied
-        const float* As = lds + (st & 1) * SUB;
-        mma_subtile_swz<BN>(As, As + BM * BKS, acc, wm, wn, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                               // all four waves' DMA has landed
+        mma_ktile_swz<BN>(As, Bs, acc, wm, wn, lane);
     }
 
     const int kh = lane >> 5, col = lane & 31;
@@ -740,55 +583,27 @@ extern "C" int ntk_vgg_pack_weights(const float* w_hwio, float* w_packed, int ci
     return NTK_OK;
 }
 
-template <int BN, bool SMALLC, int VAR>
-static void launch_conv_v(const float* in, const float* wp, const float* bias, float* out, int npatch,
-                          int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
-    const long rows = (long)npatch * 16;
-    const long rtiles = (rows + BM - 1) / BM;
-    dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
-    if (pool)
-        conv3x3_relu_kernel<BN, SMALLC, true, VAR><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-    else
-        conv3x3_relu_kernel<BN, SMALLC, false, VAR><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-}
-
-static int g_conv_variant = 4;   // tuning knob (ntk_vgg_set_conv_variant); every variant computes identical results
+static int g_conv_variant = 4;   // tuning knob (ntk_vgg_set_conv_variant): 4 LDS-DMA staging (default), 2 VGPR staging; same results
 
 template <int BN, bool SMALLC>
 static void launch_conv(const float* in, const float* wp, const float* bias, float* out, int npatch,
                         int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
+    const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
+    dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
     if constexpr (!SMALLC) {
-        if (g_conv_variant == 4 || g_conv_variant == 5) {
-            const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
-            dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
-            if (g_conv_variant == 4) {
-                if (pool) conv3x3_relu_dma_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-                else conv3x3_relu_dma_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            } else {
-                if (pool) conv3x3_relu_dma2_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-                else conv3x3_relu_dma2_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            }
-            return;
-        }
-        if (g_conv_variant == 6) {
-            const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
-            dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
-            if (pool) conv3x3_relu_dma_kernel<BN, true, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            else conv3x3_relu_dma_kernel<BN, false, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        if (g_conv_variant == 4) {
+            if (pool) conv3x3_relu_dma_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+            else conv3x3_relu_dma_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
             return;
         }
     }
-    switch (g_conv_variant) {
-        case 1: launch_conv_v<BN, SMALLC, 1>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
-        case 2: launch_conv_v<BN, SMALLC, 2>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
-        case 3: launch_conv_v<BN, SMALLC, 3>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
-        case 0: launch_conv_v<BN, SMALLC, 0>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;
-        default: launch_conv_v<BN, SMALLC, 2>(in, wp, bias, out, npatch, H, W, cin, cout, Kp, pool, st); break;   // 4 with Cin = 3
-    }
+    // VGPR-staged kernel: tiny Cin (scalar-gather loader) and variant 2
+    if (pool) conv3x3_relu_kernel<BN, SMALLC, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+    else conv3x3_relu_kernel<BN, SMALLC, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
 }
 
 extern "C" int ntk_vgg_set_conv_variant(int v) {
-    NTK_REQUIRE(v >= 0 && v <= 6, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d", v);
+    NTK_REQUIRE(v == 2 || v == 4, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d (2 or 4)", v);
     g_conv_variant = v;
     return NTK_OK;
 }
@@ -905,7 +720,7 @@ extern "C" int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_
     const int npatch = (int)npatch_l;
     const long rtiles = (npatch_l * 16 + BM - 1) / BM;
     dim3 grid((unsigned)(((rtiles + 7) / 8) * 8));
-    conv3x3_relu_kernel<64, true, false, 2, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+    conv3x3_relu_kernel<64, true, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
         in, w_packed, bias, reinterpret_cast<float*>(out_bf16), npatch, H, W, cin, cout, ntk_vgg_packed_k(cin));
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_f32_to_bf16");
     return NTK_OK;
