@@ -168,15 +168,24 @@ def gemm_tn(A, B, out, accumulate=False, splits=None, workspace=None):
 
 
 class NTMCell(object):
-    """The NTM recurrent cell (ntm_cell.py:17-315) on the HIP path."""
+    """The NTM recurrent cell (ntm_cell.py:17-315) on the HIP path.
+
+    ``controller_num_layers == 1`` (what every reference script runs, direct_offset_output.py:24) is the fused
+    persistent kernel with forward, BPTT and training.  A deeper MultiRNNCell controller (the constructor's default
+    is 10) returns a ``StackedNTMCell``: forward / step() only, lower layers as separate LSTM steps."""
+
+    def __new__(cls, output_dim=None, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=100,
+                controller_num_layers=10, *args, **kwargs):
+        if cls is NTMCell and controller_num_layers != 1:
+            return object.__new__(StackedNTMCell)
+        return object.__new__(cls)
 
     def __init__(self, output_dim, mem_size=128, mem_dim=20, shift_range=1,
                  controller_hidden_size=100, controller_num_layers=10,
                  write_head_size=3, read_head_size=3, write_first=False,
                  input_dim=None, device="cuda", init_scale=0.1, seed=None):
         if controller_num_layers != 1:
-            raise _lib.NtkError("controller_num_layers=%d: the HIP path implements the single-layer controller "
-                                "the reference scripts run (direct_offset_output.py:24)" % controller_num_layers)
+            raise _lib.NtkError("controller_num_layers=%d reached the single-layer cell" % controller_num_layers)
         self.mem_size = mem_size
         self.mem_dim = mem_dim
         self.controller_hidden_size = controller_hidden_size
@@ -372,6 +381,136 @@ class NTMCell(object):
         return (outputs[:, 0], logits[:, 0], state, debug, new["M"], new["w"], new["read"], new["controller_state"])
 
     step = __call__
+
+
+class StackedNTMCell(NTMCell):
+    """NTMCell with a MultiRNNCell controller of L > 1 BasicLSTMCell layers (ntm_cell.py:45-50, :101-105): layer 0 reads
+    concat(x, read_prev), layer k reads h_{k-1}, the top layer's h drives the heads.  Layers 0 .. L-2 run as separate
+    LSTM steps (ntk_gemm_nt_f32 + ntk_lstm_step_fwd); the top layer, the addressing and the memory update run in the
+    fused cell kernel (whose read_prev rows of the recurrent matrix are zero here, because read_prev enters at
+    layer 0).  Forward only: step() / run_sequence(); training of deep controllers is not on the HIP path.
+    controller_state layout = [c_0, h_0, c_1, h_1, ...] (state_is_tuple=False, MultiRNNCell concatenation)."""
+
+    def __init__(self, output_dim, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=100,
+                 controller_num_layers=10, write_head_size=3, read_head_size=3, write_first=False,
+                 input_dim=None, device="cuda", init_scale=0.1, seed=None):
+        self.L = int(controller_num_layers)
+        self.output_dim, self.mem_size, self.mem_dim, self.shift_range = output_dim, mem_size, mem_dim, shift_range
+        self.controller_hidden_size, self.controller_num_layers = controller_hidden_size, self.L
+        self.write_head_size, self.read_head_size, self.write_first = write_head_size, read_head_size, bool(write_first)
+        self.device, self.init_scale, self.seed = torch.device(device), init_scale, seed
+        self.top = NTMCell(output_dim, mem_size, mem_dim, shift_range, controller_hidden_size, 1, write_head_size,
+                           read_head_size, write_first, input_dim=None, device=device, init_scale=init_scale, seed=seed)
+        self.D = None
+        self.lower = []
+        if input_dim is not None:
+            self._build(int(input_dim))
+
+    dims = property(lambda self: self.top.dims)
+    params = property(lambda self: self.top.params)
+
+    def _build(self, input_dim, sd=None):
+        hid, RM, L = self.controller_hidden_size, self.read_head_size * self.mem_dim, self.L
+        self.D = int(input_dim)
+        if sd is None:
+            g = torch.Generator().manual_seed(0 if self.seed is None else int(self.seed))
+            u = lambda *shape: (torch.rand(shape, generator=g) * 2 - 1) * self.init_scale
+            tmp = NTMDims(hid, self.output_dim, self.mem_size, self.mem_dim, self.shift_range, hid, self.read_head_size,
+                          self.write_head_size)
+            sd = {"addressing/weights": u(hid, tmp.P), "addressing/biases": torch.zeros(tmp.P),
+                  "output/weights": u(hid, tmp.O), "output/biases": torch.zeros(tmp.O),
+                  "init_state/M": u(tmp.N, tmp.Md), "init_state/w": u(tmp.H, tmp.N), "init_state/read": u(tmp.R, tmp.Md)}
+            in_dim = self.D + RM
+            for k in range(L):
+                sd["lstm/cell_%d/weights" % k] = u(in_dim + hid, 4 * hid)
+                sd["lstm/cell_%d/biases" % k] = torch.zeros(4 * hid)
+                in_dim = hid
+        t = lambda v: torch.as_tensor(v, dtype=torch.float32)
+        self.lower = []
+        in_dim = self.D + RM
+        for k in range(L - 1):
+            W, b = t(sd["lstm/cell_%d/weights" % k]), t(sd["lstm/cell_%d/biases" % k])
+            assert tuple(W.shape) == (in_dim + hid, 4 * hid), W.shape
+            ld = (in_dim + hid + 3) // 4 * 4
+            WT = torch.zeros((4 * hid, ld))
+            WT[:, :in_dim + hid] = W.t()
+            self.lower.append((WT.to(self.device), b.to(self.device).contiguous(), in_dim, ld))
+            in_dim = hid
+        Wt, bt = t(sd["lstm/cell_%d/weights" % (L - 1)]), t(sd["lstm/cell_%d/biases" % (L - 1)])
+        assert tuple(Wt.shape) == (2 * hid, 4 * hid), Wt.shape
+        top_sd = {k: sd[k] for k in ("addressing/weights", "addressing/biases", "output/weights", "output/biases",
+                                      "init_state/M", "init_state/w", "init_state/read")}
+        top_sd["lstm/cell_0/weights"] = torch.cat([Wt[:hid], torch.zeros((RM, 4 * hid)), Wt[hid:]], dim=0)
+        top_sd["lstm/cell_0/biases"] = bt
+        self.top._build(hid, top_sd)
+        self._sd = {k: t(v).clone() for k, v in sd.items()}
+
+    def load_state_dict(self, sd, input_dim=None):
+        if input_dim is None:
+            input_dim = sd["lstm/cell_0/weights"].shape[0] - self.read_head_size * self.mem_dim - self.controller_hidden_size
+        self._build(int(input_dim), sd)
+
+    def state_dict(self):
+        return {k: v.clone() for k, v in self._sd.items()}
+
+    def state_placeholder(self, batch_size):
+        st = self.top.state_placeholder(batch_size)
+        st["controller_state"] = torch.empty((batch_size, 2 * self.controller_hidden_size * self.L), device=self.device)
+        return st
+
+    def zero_state(self, batch_size, initializer=None):
+        st = self.top.zero_state(batch_size)
+        st["controller_state"] = torch.zeros((batch_size, 2 * self.controller_hidden_size * self.L), device=self.device)
+        return st
+
+    def __call__(self, inputs, prev_state, M_prev=None, w_prev=None, read_prev=None, controller_state=None, scope=None):
+        if self.D is None:
+            self._build(inputs.shape[1])
+        if prev_state is not None:
+            M_prev, w_prev = prev_state["M"], prev_state["w"]
+            read_prev, controller_state = prev_state["read"], prev_state["controller_state"]
+        hid, L = self.controller_hidden_size, self.L
+        B = inputs.shape[0]
+        lib, stream = _lib.lib(), _lib.stream()
+        cs = controller_state.contiguous()
+        inp = torch.cat([inputs.to(self.device, torch.float32), read_prev.reshape(B, -1)], dim=1)
+        new_cs = []
+        for k, (WT, bias, in_dim, ld) in enumerate(self.lower):
+            buf = torch.zeros((B, ld), device=self.device)
+            buf[:, :in_dim] = inp
+            buf[:, in_dim:in_dim + hid] = cs[:, 2 * hid * k + hid:2 * hid * (k + 1)]
+            pre = gemm_nt(buf, WT, bias)
+            c_prev = cs[:, 2 * hid * k:2 * hid * k + hid].contiguous()
+            c, h = torch.empty((B, hid), device=self.device), torch.empty((B, hid), device=self.device)
+            _lib.check(lib.ntk_lstm_step_fwd(_P(pre), _P(c_prev), 0.0, _P(c), _P(h), None, B, hid, stream), "ntk_lstm_step_fwd")
+            new_cs += [c, h]
+            inp = h
+        top_state = {"M": M_prev, "w": w_prev, "read": read_prev,
+                     "controller_state": cs[:, 2 * hid * (L - 1):].contiguous()}
+        out, logit, st, debug, M, w, read, top_cs = self.top(inp, top_state)
+        full_cs = torch.cat(new_cs + [top_cs], dim=1)
+        st = dict(st)
+        st["controller_state"] = full_cs
+        return (out, logit, st, debug, M, w, read, full_cs)
+
+    step = __call__
+
+    def run_sequence(self, X, state, record=False, want_outputs=True, after_projection=None):
+        """Python loop over step() (the LoopNTMTracker fallback for deep controllers)."""
+        if record:
+            raise _lib.NtkError("StackedNTMCell: BPTT records are not available for controller_num_layers > 1")
+        B, S, _ = X.shape
+        logits, outs = [], []
+        for t in range(S):
+            r = self(X[:, t, :self.D], state)
+            outs.append(r[0]); logits.append(r[1]); state = r[2]
+        return torch.stack(logits, 1), (torch.stack(outs, 1) if want_outputs else None), state, {}
+
+    def _pad_inputs(self, inputs):
+        return inputs
+
+    def backward_sequence(self, *a, **k):
+        raise _lib.NtkError("training of controller_num_layers > 1 is not implemented on the HIP path")
 
 
 class LoopNTMTracker(object):

@@ -115,8 +115,12 @@ def test_zero_state_matches_oracle(cuda):
 def test_unsupported_configs_fail_loudly(cuda):
     from ntmtrack.ntm import NTMCell
     from ntmtrack._lib import NtkError
+    deep = NTMCell(2, controller_num_layers=3, mem_size=64, mem_dim=8, controller_hidden_size=16, write_head_size=1,
+                   read_head_size=1, input_dim=6, device=cuda)
+    with pytest.raises(NtkError):                                   # deep controllers: forward only
+        deep.run_sequence(torch.zeros((1, 2, 6), device=cuda), deep.zero_state(1), record=True)
     with pytest.raises(NtkError):
-        NTMCell(2, controller_num_layers=10, device=cuda)          # reference default; HIP path is single-layer
+        deep.backward_sequence()
     cell = NTMCell(2, mem_size=100, mem_dim=20, controller_hidden_size=64, controller_num_layers=1,
                    write_head_size=1, read_head_size=1, input_dim=8, device=cuda)
     with pytest.raises(NtkError):                                   # mem_size must be a multiple of 64
@@ -144,3 +148,48 @@ def test_full_length_sequence_drift(cuda):
     err = np.max(np.abs(np.tanh(l_gpu.cpu().numpy()) - np.tanh(logits)))
     assert err < 1e-4, err
     assert np.max(np.abs(trk.last_state["M"].cpu().numpy() - fin["M"])) < 1e-4
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+def test_multilayer_controller_steps_match_oracle(cuda, layers):
+    """MultiRNNCell controller with L > 1 BasicLSTMCell layers (ntm_cell.py:45-50, :101-105; the constructor default is
+    10): StackedNTMCell steps -- lower layers as LSTM steps, top layer + addressing in the fused kernel -- against the
+    oracle, chained over 5 steps (state layout [c_0, h_0, c_1, h_1, ...])."""
+    from ntmtrack.ntm import NTMCell, StackedNTMCell
+    rng = np.random.default_rng(31)
+    cfg = O.NTMConfig(11, 3, mem_size=64, mem_dim=12, shift_range=1, controller_hidden_size=24, controller_num_layers=layers,
+                      write_head_size=2, read_head_size=2)
+    params = O.init_params(cfg, rng, scale=0.3)
+    for k in params:
+        if k.endswith("biases"):
+            params[k] = rng.uniform(-0.2, 0.2, size=params[k].shape).astype(np.float32)
+    cell = NTMCell(3, mem_size=64, mem_dim=12, shift_range=1, controller_hidden_size=24, controller_num_layers=layers,
+                   write_head_size=2, read_head_size=2, device=cuda)
+    assert isinstance(cell, StackedNTMCell)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    B = 3
+    st = cell.zero_state(B)
+    ost = O.zero_state(cfg, params, B)
+    assert st["controller_state"].shape == (B, 2 * 24 * layers)
+    for t in range(5):
+        x = rng.standard_normal((B, 11)).astype(np.float32)
+        out, logit, st, _dbg, M, w, read, cs = cell(torch.from_numpy(x).to(cuda), st)
+        oout, ologit, ost, _ = O.ntm_step(cfg, params, x, ost)
+        np.testing.assert_allclose(logit.cpu().numpy(), ologit, atol=2e-5)
+        np.testing.assert_allclose(out.cpu().numpy(), oout, atol=2e-5)
+        np.testing.assert_allclose(cs.cpu().numpy(), ost["controller_state"], atol=2e-5)
+        np.testing.assert_allclose(M.cpu().numpy(), ost["M"], atol=2e-5)
+        np.testing.assert_allclose(w.cpu().numpy(), ost["w"], atol=2e-5)
+        np.testing.assert_allclose(read.cpu().numpy(), ost["read"], atol=2e-5)
+    sd = cell.state_dict()
+    assert set(sd) == set(params) and all(np.array_equal(sd[k].numpy(), params[k]) for k in params)
+    # LoopNTMTracker over a deep cell = Python loop over step()
+    from ntmtrack.ntm import LoopNTMTracker
+    trk = LoopNTMTracker(4, 3, None, mem_size=64, mem_dim=12, shift_range=1, controller_hidden_size=24,
+                         controller_num_layers=layers, write_head_size=2, read_head_size=2, device=cuda)
+    trk.cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    xs = rng.standard_normal((B, 4, 11)).astype(np.float32)
+    outs, logits = trk(torch.from_numpy(xs).to(cuda))
+    oouts, ologits, _ = O.loop_ntm_tracker(cfg, params, xs)
+    np.testing.assert_allclose(logits.cpu().numpy(), ologits, atol=3e-5)
+    np.testing.assert_allclose(outs.cpu().numpy(), oouts, atol=3e-5)
