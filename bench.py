@@ -29,6 +29,7 @@ import torch
 # (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
 TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd": 8.5051e10 + 2.3121e10}
+NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.451e8 + 1.036e9     # profiles/r01_ntm_seq_hbm_traffic_pmc.csv
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
@@ -133,6 +134,8 @@ def memory_step_probe(trk, model, gts0, B, T):
             "algorithmic_bytes_per_sequence_step": per_step, "sequences": B, "steps": S,
             "forward_ms": round(ms, 3), "us_per_step": round(ms * 1e3 / S, 3),
             "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5),
+            "traffic": (NTM_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)) if model == "ntm" else None,
+            "traffic_note": "HBM-side bytes of the training-mode forward kernel (PMC, profiles/r01_ntm_seq_hbm_traffic_pmc.csv): input projection read + per-step BPTT records written; the memory state itself never leaves LDS",
             "note": "serialise + input projection + persistent sequence kernel, one workgroup per sequence; state is LDS/L2 resident"}
 
 
