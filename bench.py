@@ -296,8 +296,8 @@ def main():
                          "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv; direct kernels: r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
                          "algorithmic_flops_per_frame": conv_flops_per_frame(),
                          "note": ("achieved = ALGORITHMIC direct-convolution flops (SURVEY 8d: 27.92 GFLOP/frame, independent of the "
-                                  "algorithm) / trunk time; the Winograd kernel executes 2.25x fewer multiplies on 28 of 32 MFMA rows "
-                                  "(executed MFMA flops = algorithmic x 0.508), so frac may exceed 1 against the fp32 MFMA peak")
+                                  "algorithm) / trunk time; the Winograd kernel executes 2.25x fewer multiplies "
+                                  "(executed MFMA flops = algorithmic x 0.444; MFMA pipe ~66 % busy, profiles/), so frac may exceed 1 against the fp32 MFMA peak")
                                  if (args.conv_algo == "winograd" and args.conv_dtype == "f32") else "direct convolution: executed = algorithmic flops"},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},
