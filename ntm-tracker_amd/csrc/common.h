@@ -55,3 +55,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
 }
+
+// Streaming mat-vec slice: sum_{r = r0}^{r1 - 1} x[r] * w4[r * stride4] with two register batches of PF rows in flight.
+// Written out explicitly because the compiler, left alone, sinks every load to just before its use (one 16-byte
+// load in flight per thread): fine while the weights hit L2, 2.5-2.8x slower when a concurrent kernel evicts them.
+// rlast = last row index that may be read (rows past r1 are only prefetched, never used).
+template <int PF>
+__device__ __forceinline__ f32x4 ntk_stream_matvec(const f32x4* __restrict__ w4, int stride4, const float* __restrict__ x,
+                                                   int r0, int r1, int rlast) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wa[PF], wb[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) wa[q] = w4[(size_t)min(r0 + q, rlast) * stride4];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) wb[q] = w4[(size_t)min(r0 + PF + q, rlast) * stride4];
+    for (int r = r0; r < r1; r += 2 * PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) acc += ((r + q < r1) ? x[r + q] : 0.f) * wa[q];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) wa[q] = w4[(size_t)min(r + 2 * PF + q, rlast) * stride4];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) acc += ((r + PF + q < r1) ? x[r + PF + q] : 0.f) * wb[q];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) wb[q] = w4[(size_t)min(r + 3 * PF + q, rlast) * stride4];
+    }
+    return acc;
+}

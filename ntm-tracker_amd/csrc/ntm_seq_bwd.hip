@@ -412,11 +412,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         if (tid < nslH * hg4) {
             const int cg = tid % hg4, sl = tid / hg4;
             const int c0 = sl * nperH, c1 = min(PP, c0 + nperH);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.WaT) + (size_t)c0 * hg4 + cg;
-#pragma unroll 4
-            for (int c = c0; c < c1; ++c, wp4 += hg4) acc += sDU[c] * (*wp4);
-            sPart4[sl * hg4 + cg] = acc;
+            sPart4[sl * hg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 4)>(reinterpret_cast<const f32x4*>(a.WaT) + cg, hg4, sDU, c0, c1, PP - 1);
         }
         __syncthreads();
         // ------------------------------------------------ B10: LSTM cell backward
@@ -441,11 +437,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         if (tid < nslZ * kg4) {
             const int cg = tid % kg4, sl = tid / kg4;
             const int r0 = sl * nperZ, r1 = min(4 * hid, r0 + nperZ);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.WrT) + (size_t)r0 * kg4 + cg;
-#pragma unroll 8
-            for (int r = r0; r < r1; ++r, wp4 += kg4) acc += sDG[r] * (*wp4);
-            sPart4[sl * kg4 + cg] = acc;
+            sPart4[sl * kg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 4)>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, r0, r1, 4 * hid - 1);
         }
         __syncthreads();
         if (tid < K) {
