@@ -212,15 +212,8 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
         if (tid < nslB * ncg) {
             const int cg = tid % ncg, ks = tid / ncg;
             const int k0 = ks * kperB, k1 = min(hid, k0 + kperB);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* wp = Wa4 + (size_t)k0 * ncg + cg;
-#pragma unroll 4
-            for (int k = k0; k < k1; ++k, wp += ncg) {
-                const float hk = sZ[RM + k];
-                const f32x4 w = *wp;
-                acc += hk * w;
-            }
-            sPart4[ks * ncg + cg] = acc;
+            // explicit two-batch stream (the compiler otherwise keeps ONE load in flight, see common.h)
+            sPart4[ks * ncg + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 4)>(Wa4 + cg, ncg, sZ + RM, k0, k1, hid);
         }
         __syncthreads();
         // ------------------------------------------------------------ P4: control activations
