@@ -437,7 +437,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         if (tid < nslZ * kg4) {
             const int cg = tid % kg4, sl = tid / kg4;
             const int r0 = sl * nperZ, r1 = min(4 * hid, r0 + nperZ);
-            sPart4[sl * kg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 4)>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, r0, r1, 4 * hid - 1);
+            sPart4[sl * kg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 8)>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, r0, r1, 4 * hid - 1);
         }
         __syncthreads();
         if (tid < K) {
