@@ -32,7 +32,7 @@ struct NtmBwdArgs {
 
 struct NtmBwdLds {
     int part, dM, G, Mp, Mt, dW, Wp, Wt, Wc, Wv, Wg, Dwv, Dsim, U, DU, DG, dZ, dC, Gt, Ct, Cp,
-        Khat, Ks, Kinv, Kss, Cinv, Css, C2, Dkhat, Sw, Red, total;
+        Khat, Ks, Kinv, Kss, Cinv, Css, C2, Dkhat, Sw, Red, Dmh, total;
 };
 
 constexpr int NQ = 6;        // max simultaneous per-head reductions in one stage
@@ -42,7 +42,7 @@ constexpr int MAXM = 8;      // max memory elements prefetched per thread
 
 static void ntm_bwd_lds(const NtmDims& d, int T, int ldkT, int ldhT, NtmBwdLds& L) {
     const int MP = d.Md | 1, NM = d.N * MP, HN = d.H * d.N;
-    const int nout = d.H * d.Md + d.Md + 2 * d.Wh * d.Md;
+    const int nout = d.H * d.Md + 2 * d.Wh * d.Md;
     const int nslP = ntm_imin(ntm_imax(1, T / nout), d.N);
     const int nslZ = ntm_imax(1, T / (ldkT / 4));
     const int nslH = ntm_imax(1, T / (ldhT / 4));
@@ -62,6 +62,7 @@ static void ntm_bwd_lds(const NtmDims& d, int T, int ldkT, int ldhT, NtmBwdLds& 
     L.Cinv = take(d.Md); L.Css = take(d.Md); L.C2 = take(d.Md); L.Dkhat = take(d.H * d.Md);
     L.Sw = take(d.H * d.SS);
     L.Red = take(d.H * NQT * (d.N / 64));
+    L.Dmh = take(d.N * (d.Md | 1));
     L.total = o;
 }
 
@@ -92,14 +93,14 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
     float* sdC = smem + L.dC;  float* sGt = smem + L.Gt; float* sCt = smem + L.Ct; float* sCp = smem + L.Cp;
     float* sKhat = smem + L.Khat; float* sKs = smem + L.Ks; float* sKinv = smem + L.Kinv; float* sKss = smem + L.Kss;
     float* sCinv = smem + L.Cinv; float* sCss = smem + L.Css; float* sC2 = smem + L.C2; float* sDkhat = smem + L.Dkhat;
-    float* sSw = smem + L.Sw;  float* sRed = smem + L.Red;
+    float* sSw = smem + L.Sw;  float* sRed = smem + L.Red;  float* sDmh = smem + L.Dmh;
     f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
 
     // thread roles
     int hh = tid / N, nn = tid - hh * N;                // (head, slot) owner; active iff hh < H
     bool hn = hh < H;
     int wi = nn >> 6;
-    const int nout = H * Md + Md + 2 * Wh * Md;
+    const int nout = H * Md + 2 * Wh * Md;
     const int nslP = min(max(1, T / nout), N);
     const int nperP = (N + nslP - 1) / nslP;
     const int kg4 = ldkT >> 2, hg4 = ldhT >> 2;
@@ -335,7 +336,15 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             for (int j = 0; j < NQ - 1; ++j) if (j < SS) sDU[d.oS + h * SS + j] = sSw[h * SS + j] * (Ssw[j] - dot);
         }
 
-        // ------------------------------------------------ B7: reductions over slots (keys, column norms, erase, add)
+        // ------------------------------------------------ B7: dMhat[n][m] = sum_h dsim[h][n] khat[h][m], computed ONCE
+        //                                                  (the column-norm sum and the d(M_prev) update both use it);
+        //                                                  reductions over slots (keys, erase, add)
+        for (int idx = tid; idx < NMd; idx += T) {
+            const int n = idx / Md, m = idx - n * Md;
+            float dmh = 0.f;
+            for (int h = 0; h < H; ++h) dmh += sDsim[h * N + n] * sKhat[h * Md + m];
+            sDmh[n * MP + m] = dmh;
+        }
         if (tid < nslP * nout) {
             const int o = tid % nout, sl = tid / nout;
             const int n0 = sl * nperP, n1 = min(N, n0 + nperP);
@@ -343,15 +352,8 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             if (o < H * Md) {                                  // sum_n dsim[h][n] * M_prev[n][m]
                 const int h = o / Md, m = o - h * Md;
                 for (int n = n0; n < n1; ++n) s += sDsim[h * N + n] * sMp[n * MP + m];
-            } else if (o < H * Md + Md) {                      // sum_n dMhat[n][m] * M_prev[n][m]
-                const int m = o - H * Md;
-                for (int n = n0; n < n1; ++n) {
-                    float dmh = 0.f;
-                    for (int h = 0; h < H; ++h) dmh += sDsim[h * N + n] * sKhat[h * Md + m];
-                    s += dmh * sMp[n * MP + m];
-                }
             } else {
-                const int o2 = o - H * Md - Md;
+                const int o2 = o - H * Md;
                 const int which = o2 / (Wh * Md);              // 0: erase, 1: add
                 const int jm = o2 - which * Wh * Md;
                 const int j = jm / Md, m = jm - j * Md;
@@ -371,17 +373,23 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             sPart[sl * nout + o] = s;
         }
         __syncthreads();
+        // column-norm term: s_m = sum_n dMhat[n][m] * M_prev[n][m], one wave_sum per column (waves stride over m)
+        for (int m = (tid >> 6); m < Md; m += (T >> 6)) {
+            float s = 0.f;
+            for (int n = lane; n < N; n += 64) s += sDmh[n * MP + m] * sMp[n * MP + m];
+            s = wave_sum(s);
+            if (lane == 0) {
+                const float ci = sCinv[m];
+                sC2[m] = (sCss[m] > 1e-12f) ? -ci * ci * ci * s : 0.f;   // dM += M * C2 (2 * d css)
+            }
+        }
         if (tid < nout) {
             float s = 0.f;
             for (int sl = 0; sl < nslP; ++sl) s += sPart[sl * nout + tid];
             if (tid < H * Md) {
                 sDkhat[tid] = s * sCinv[tid % Md];
-            } else if (tid < H * Md + Md) {
-                const int m = tid - H * Md;
-                const float ci = sCinv[m];
-                sC2[m] = (sCss[m] > 1e-12f) ? -ci * ci * ci * s : 0.f;   // dM += M * C2 (2 * d css)
             } else {
-                const int o2 = tid - H * Md - Md;
+                const int o2 = tid - H * Md;
                 const int which = o2 / (Wh * Md);
                 const int jm = o2 - which * Wh * Md;
                 if (which == 0) { const float e = sU[d.oE + jm]; sDU[d.oE + jm] = s * e * (1.0f - e); }
@@ -401,9 +409,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         for (int idx = tid; idx < NMd; idx += T) {
             const int n = idx / Md, m = idx - n * Md, ai = n * MP + m;
-            float dmh = 0.f;
-            for (int h = 0; h < H; ++h) dmh += sDsim[h * N + n] * sKhat[h * Md + m];
-            sdM[ai] += sCinv[m] * dmh + sMp[ai] * sC2[m];
+            sdM[ai] += sCinv[m] * sDmh[ai] + sMp[ai] * sC2[m];
         }
         __syncthreads();
         if (tid < PP) a.du[bt * PP + tid] = sDU[tid];
