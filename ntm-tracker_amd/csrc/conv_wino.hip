@@ -20,6 +20,10 @@
 // Results differ from the direct kernel by rounding only (different summation order, ~1e-6 relative per layer).
 #include "common.h"
 
+#ifndef WINO_UD
+#define WINO_UD 3      // U prefetch distance in planes (1..3)
+#endif
+
 namespace {
 
 constexpr int WT = 256;            // threads
@@ -210,13 +214,19 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     // operand registers ping-pong by plane parity (4 planes per chunk: the parity carries over chunk boundaries),
     // so a prefetch lands in the registers its MFMAs read -- no copies.  The loop body is branch-free: the last
     // iteration harmlessly re-requests chunk 0's U, re-stages the last patch and re-transforms it.
-    f32x4 Bq[2][2], Aq[2];                      // [parity][column block], [parity]
+    // U (B operand) ring of four register sets, one per plane index: plane j + UD is requested while plane j multiplies
+    // (UD planes = UD x 512 MFMA cycles of cover for an L2 round trip; with UD = 1 the wave parks on every plane).
+    constexpr int UD = WINO_UD;
+    f32x4 Bq[4][2], Aq[2];                      // [plane][column block], [parity]
     const unsigned uw = __builtin_amdgcn_readfirstlane((unsigned)wave);
     // wave-uniform base of this wave's 8 KB of fragments for K step c8: ubase + c8 * 8192 floats
     const float* ubase = a.U + ((size_t)cb * n8 * 4 + uw) * 2048;
     const unsigned ulane = (unsigned)lane * 4u;
-    Bq[0][0] = *reinterpret_cast<const f32x4*>(ubase + ulane);
-    Bq[0][1] = *reinterpret_cast<const f32x4*>(ubase + 256 + ulane);
+#pragma unroll
+    for (int j = 0; j < UD; ++j) {
+        Bq[j][0] = *reinterpret_cast<const f32x4*>(ubase + j * 512 + ulane);
+        Bq[j][1] = *reinterpret_cast<const f32x4*>(ubase + j * 512 + 256 + ulane);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     for (int c8 = 0; c8 < n8; ++c8) {
@@ -230,17 +240,18 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
         Aq[0] = *reinterpret_cast<const f32x4*>(vcur);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float* up = (j < 3) ? uc + (j + 1) * 512 : un;
-            Bq[(j + 1) & 1][0] = *reinterpret_cast<const f32x4*>(up + ulane);
-            Bq[(j + 1) & 1][1] = *reinterpret_cast<const f32x4*>(up + 256 + ulane);
+            const int jn = j + UD;                                  // plane requested now
+            const float* up = (jn < 4) ? uc + jn * 512 : un + (jn - 4) * 512;
+            Bq[jn & 3][0] = *reinterpret_cast<const f32x4*>(up + ulane);
+            Bq[jn & 3][1] = *reinterpret_cast<const f32x4*>(up + 256 + ulane);
             if (j < 3) Aq[(j + 1) & 1] = *reinterpret_cast<const f32x4*>(vcur + (j + 1) * 32 * RSV2);
             if (j == 0) tr_load((c8 + 1) & 1);          // next chunk's window reads ...
             if (j == 2) tr_store((c8 + 1) & 1);         // ... become its V two planes of MFMAs later
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[j & 1][q], Bq[j & 1][0][q], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[j & 1][q], Bq[j & 1][1][q], acc[j][1], 0, 0, 0);
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[j & 1][q], Bq[j][0][q], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[j & 1][q], Bq[j][1][q], acc[j][1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
