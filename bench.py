@@ -28,7 +28,7 @@ import torch
 # counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv
 # (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
-TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd": 8.5051e10 + 2.3121e10}
+TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd": 8.3752e10 + 2.3121e10}
 NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.451e8 + 1.036e9     # profiles/r01_ntm_seq_hbm_traffic_pmc.csv
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
