@@ -47,10 +47,8 @@ def synth_inputs(B, T, device, seed):
     for i in range(0, B * T, 64):
         n = min(64, B * T - i)
         frames[i:i + n] = torch.rand((n, 224, 224, 3), generator=g) * 255.0 - mean
-    y, x = np.ogrid[-3.5:4.5, -3.5:4.5]
-    hm = np.exp(-(x * x + y * y) / 2.0)
-    hm[hm < np.finfo(hm.dtype).eps * hm.max()] = 0
-    hm /= hm.sum()
+    from ntmtrack.geometry import discrete_gauss
+    hm = discrete_gauss((.5, .5), (8, 8), 1.0)
     gts0 = torch.from_numpy(np.tile(hm.reshape(1, 64), (B, 1)).astype(np.float32))
     offs = torch.rand((B, T, 2), generator=g) - 0.5
     offs[:, 0, :] = 0
@@ -67,27 +65,39 @@ def vgg_weights(seed):
     return ws
 
 
-def cpu_baseline(ws, n_vgg_frames=4, T=20):
-    """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded
-    sample: VGG trunk on `n_vgg_frames` frames (torch-CPU conv2d, the op granularity TF-CPU would
-    run) + NTM forward + BPTT of ONE sequence of T frames (torch-CPU autograd restatement),
-    combined as frames/s of one sequence: T / (T * t_vgg_per_frame + t_ntm_per_sequence)."""
-    from oracle import ntm_oracle as O
-    from oracle import ntm_oracle_torch as OT
+def host_cpu_info():
+    """CPU model, sockets and physical cores of this box from /proc/cpuinfo."""
+    model, cores = "unknown", set()
     try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))      # the box's CPU share for one GPU is 16 cores
-    torch.set_num_threads(cores)
-    log("cpu_baseline: %d threads" % cores)
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return {"cpu_model": model, "sockets": len({p for p, _ in cores}) or None, "physical_cores": len(cores) or None,
+            "logical_cpus": os.cpu_count()}
+
+
+def _cpu_sample(ws, threads, n_vgg_frames, T, O, OT):
+    torch.set_num_threads(threads)
     rng = np.random.default_rng(42)
     frames = (rng.uniform(0, 255, size=(n_vgg_frames, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)
     OT.vgg16_conv43(frames[:1], ws)            # warm the conv primitives
     t0 = time.perf_counter()
-    fm = OT.vgg16_conv43(frames, ws)
+    OT.vgg16_conv43(frames, ws)
     t_vgg = (time.perf_counter() - t0) / n_vgg_frames
-    log("cpu_baseline: VGG %.3f s/frame" % t_vgg)
     cfg = O.NTMConfig(514, 2, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=200,
                       controller_num_layers=1, write_head_size=1, read_head_size=4)
     params = O.init_params(cfg, rng)
@@ -97,12 +107,33 @@ def cpu_baseline(ws, n_vgg_frames=4, T=20):
     t0 = time.perf_counter()
     OT.loss_and_grads(cfg, params, x, offs, dtype=torch.float32)
     t_ntm = time.perf_counter() - t0
-    log("cpu_baseline: NTM fwd+bwd %.2f s/sequence" % t_ntm)
-    fps = T / (T * t_vgg + t_ntm)
-    return {"value": round(fps, 3), "unit": "frames/sec", "cores": cores, "kind": "port",
-            "sample": "VGG conv1_1..conv4_3 on %d frames (torch-CPU conv2d, %.3f s/frame) + NTM fwd+BPTT of 1 "
-                      "sequence x %d frames (torch-CPU autograd restatement, %.2f s); frames/s of one sequence"
-                      % (n_vgg_frames, t_vgg, T, t_ntm)}
+    log("cpu_baseline: %d thread(s): VGG %.3f s/frame, NTM fwd+BPTT %.2f s/sequence" % (threads, t_vgg, t_ntm))
+    return T / (T * t_vgg + t_ntm), t_vgg, t_ntm
+
+
+def cpu_baseline(ws, n_vgg_frames=8, T=20):
+    """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample of the same
+    workload: VGG trunk on `n_vgg_frames` frames (torch-CPU conv2d, the op granularity TF-CPU would run) + NTM
+    forward + BPTT of ONE sequence of T frames (torch-CPU autograd restatement), combined as frames/s of one
+    sequence: T / (T * t_vgg_per_frame + t_ntm_per_sequence).  Run with all usable cores and once single-threaded."""
+    from oracle import ntm_oracle as O
+    from oracle import ntm_oracle_torch as OT
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the box's CPU share for one GPU is 16 cores
+    fps, t_vgg, t_ntm = _cpu_sample(ws, cores, n_vgg_frames, T, O, OT)
+    fps1, t_vgg1, t_ntm1 = _cpu_sample(ws, 1, 2, T, O, OT)
+    torch.set_num_threads(cores)
+    out = {"value": round(fps, 3), "unit": "frames/sec", "cores": cores, "kind": "port",
+           "sample": "VGG conv1_1..conv4_3 on %d frames (torch-CPU conv2d, %.3f s/frame) + NTM fwd+BPTT of 1 "
+                     "sequence x %d frames (torch-CPU autograd restatement, %.2f s); frames/s of one sequence"
+                     % (n_vgg_frames, t_vgg, T, t_ntm),
+           "single_thread": {"value": round(fps1, 3), "unit": "frames/sec", "vgg_s_per_frame": round(t_vgg1, 3),
+                             "ntm_s_per_sequence": round(t_ntm1, 2)}}
+    out.update(host_cpu_info())
+    return out
 
 
 def memory_step_probe(trk, model, gts0, B, T):
@@ -267,7 +298,13 @@ def main():
         vgg_ms = float(np.mean([a.elapsed_time(b) for a, b in marks_vgg]))
         ntm_ms = float(np.mean([a.elapsed_time(b) for a, b in marks_ntm])) if marks_ntm else 0.0
         flops = conv_flops_per_frame() * B * T
-        achieved = flops / (vgg_ms * 1e-3) / 1e12
+        algorithmic = flops / (vgg_ms * 1e-3) / 1e12
+        # executed MFMA flops: conv1_1 runs the direct kernel; the nine Winograd F(2x2,3x3) layers execute 16 multiplies
+        # per 2x2 output tile and channel pair where the direct form has 36 (x 4/9)
+        c11 = 2 * 224 * 224 * 9 * 3 * 64 * B * T
+        wino = args.conv_algo == "winograd" and args.conv_dtype == "f32"
+        executed_flops = (c11 + (flops - c11) * 4.0 / 9.0) if wino else flops
+        achieved = executed_flops / (vgg_ms * 1e-3) / 1e12
         PEAK = FP32_MFMA_PEAK_TFLOPS if args.conv_dtype == "f32" else 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
         out = {
             "metric": ("frames/sec (whole node) VGG16+NTM(128x20) seq_len=%d" % T) if args.model == "ntm" else
@@ -295,10 +332,12 @@ def main():
                          if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo]) else None,
                          "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv; direct kernels: r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
                          "algorithmic_flops_per_frame": conv_flops_per_frame(),
-                         "note": ("achieved = ALGORITHMIC direct-convolution flops (SURVEY 8d: 27.92 GFLOP/frame, independent of the "
-                                  "algorithm) / trunk time; the Winograd kernel executes 2.25x fewer multiplies "
-                                  "(executed MFMA flops = algorithmic x 0.444; MFMA pipe ~66 % busy, profiles/), so frac may exceed 1 against the fp32 MFMA peak")
-                                 if (args.conv_algo == "winograd" and args.conv_dtype == "f32") else "direct convolution: executed = algorithmic flops"},
+                         "executed_flops_per_frame": executed_flops / (B * T),
+                         "algorithmic_tflops": round(algorithmic, 2),
+                         "note": ("achieved / frac = EXECUTED MFMA flops (conv1_1 direct + 4/9 of the direct-convolution count for the "
+                                  "nine Winograd layers) / trunk time measured with HIP events on the trunk's stream inside the timed "
+                                  "region; algorithmic_tflops = the direct-convolution count (SURVEY 8d: 27.92 GFLOP/frame) / the same time")
+                                 if wino else "direct convolution: executed = algorithmic flops"},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},
         }

@@ -15,7 +15,9 @@
  *   - return value: NTK_OK (0) or a negative NTK_ERR_* code;
  *     ntk_last_error() returns a thread-local description of the last failure;
  *   - shapes are validated on the host before any launch: a bad shape is
- *     refused (NTK_ERR_BAD_SHAPE / NTK_ERR_UNSUPPORTED), never launched.
+ *     refused (NTK_ERR_BAD_SHAPE / NTK_ERR_UNSUPPORTED), never launched;
+ *   - stateless and re-entrant: no mutable process-global switches; the only
+ *     global state is a per-device cache of one-time kernel attributes.
  */
 #ifndef NTMTRACK_H_
 #define NTMTRACK_H_
@@ -63,7 +65,6 @@ int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, const float
  * last layer feeding the memory cell).  Cin a multiple of 64.  Packed weights: bf16 [Cout][9*Cin],
  * k = (c/64)*576 + (ky*3+kx)*64 + c%64.  conv1_1 (Cin = 3) runs the fp32 kernel on the fp32 frames and
  * stores bf16 (ntk_vgg_conv3x3_relu_f32_to_bf16, fp32 packed weights from ntk_vgg_pack_weights). */
-int ntk_vgg_set_bf16_conv_variant(int variant);   /* 1 (default) LDS-DMA staging, 0 VGPR staging; same results */
 int ntk_vgg_pack_weights_bf16(const float* w_hwio, void* w_packed_bf16, int cin, int cout, void* stream);
 int ntk_vgg_conv3x3_relu_bf16(const void* in_bf16, const void* w_packed_bf16, const float* bias, void* out,
                               int frames, int H, int W, int cin, int cout, int fuse_pool, int out_f32,
@@ -74,9 +75,9 @@ int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, con
 /* The same operator by fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (2.25x fewer multiplies; results equal to
  * ntk_vgg_conv3x3_relu_f32 up to rounding, ~1e-6 relative per layer).  Weights: U = G g G^T for the 16 transform
  * planes, packed lane-major for the MFMA B operand (ntk_vgg_wino_packed_floats(cin, cout) = 16*cin*cout floats).
- * cin a multiple of 16, cout a multiple of 64 (64, 128, 256 or a multiple of 512); H and W multiples of 4. */
+ * cin a multiple of 16 and at most 1024, cout a multiple of 64 (64, 128, 256 or a multiple of 512); H and W multiples
+ * of 4. */
 size_t ntk_vgg_wino_packed_floats(int cin, int cout);
-int ntk_vgg_set_wino_variant(int variant);        /* tuning knob for tile grids like 14x14: 1 (default) 2x2x8 tile blocks, 0 14x2; same results */
 int ntk_vgg_pack_weights_wino(const float* w_hwio, float* u_packed, int cin, int cout, void* stream);
 int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                   int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream);
@@ -85,10 +86,6 @@ int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_packed, const 
  * The trunk fuses the pool into the epilogue of conv1_2 / conv2_2 / conv3_3 (fuse_pool); this entry point is the
  * un-fused form with identical results.  H, W even; C a multiple of 4. */
 int ntk_maxpool2x2(const float* in, float* out, int frames, int H, int W, int C, void* stream);
-
-/* Tuning knob of the direct kernel: 4 (default) LDS-DMA staging, swizzled un-padded LDS image, 4 workgroups per CU;
- * 2 VGPR staging, one padded LDS buffer, 3 workgroups per CU.  Bit-identical results; rates in DESIGN.md. */
-int ntk_vgg_set_conv_variant(int variant);
 
 /* ------------------------------------------------------------------------
  * plain fp32 GEMMs used around the NTM recurrence (hoisted LSTM input

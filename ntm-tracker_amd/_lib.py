@@ -25,10 +25,8 @@ def _sig(lib):
         "ntk_version": (c_int, []),
         "ntk_last_error": (ctypes.c_char_p, []),
         "ntk_vgg_packed_k": (c_int, [c_int]),
-        "ntk_vgg_set_conv_variant": (c_int, [c_int]),
         "ntk_vgg_pack_weights": (c_int, [P, P, c_int, c_int, P]),
         "ntk_vgg_conv3x3_relu_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-        "ntk_vgg_set_bf16_conv_variant": (c_int, [c_int]),
         "ntk_vgg_pack_weights_bf16": (c_int, [P, P, c_int, c_int, P]),
         "ntk_vgg_conv3x3_relu_bf16": (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
         "ntk_vgg_conv3x3_relu_f32_to_bf16": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
@@ -59,7 +57,6 @@ def _sig(lib):
         "ntk_ntm_step_bwd": (c_int, [c_int] * 9 + [P, c_int, P, c_int] + [P] * 22),
         "ntk_lstm_step_fwd": (c_int, [P, P, ctypes.c_float, P, P, P, c_int, c_int, P]),
         "ntk_lstm_step_bwd": (c_int, [P] * 7 + [c_int, c_int, P]),
-        "ntk_vgg_set_wino_variant": (c_int, [c_int]),
         "ntk_vgg_wino_packed_floats": (ctypes.c_size_t, [c_int, c_int]),
         "ntk_vgg_pack_weights_wino": (c_int, [P, P, c_int, c_int, P]),
         "ntk_vgg_conv3x3_relu_wino_f32": (c_int, [P] * 4 + [c_int] * 6 + [P]),

@@ -30,6 +30,25 @@ void ntk_set_error(const char* fmt, ...);
 
 static inline bool ntk_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER
+// DEVICE.  The only global state of the library is this read-only-after-first-use per-device cache.
+struct NtkLdsAttrCache {
+    unsigned long long done = 0;     // bit d: attribute set on device d (benign race: setting it twice is harmless)
+};
+static inline int ntk_raise_lds_limit(NtkLdsAttrCache& cache, const void* const* kernels, int n, const char* who) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev >= 0 && dev < 64 && ((__atomic_load_n(&cache.done, __ATOMIC_RELAXED) >> dev) & 1ull)) return NTK_OK;
+    for (int i = 0; i < n && e == hipSuccess; ++i)
+        e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        ntk_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+        return NTK_ERR_HIP;
+    }
+    if (dev >= 0 && dev < 64) __atomic_fetch_or(&cache.done, 1ull << dev, __ATOMIC_RELAXED);
+    return NTK_OK;
+}
+
 // wave64 reductions on the DPP data path (no LDS crossbar traffic): butterfly inside each row of 16 lanes with
 // quad_perm / row_half_mirror / row_mirror, then the four row totals are read with v_readlane.  The result is
 // wave-uniform.  (__shfl_xor lowers to ds_bpermute_b32 on gfx950: ~5x the latency per step.)

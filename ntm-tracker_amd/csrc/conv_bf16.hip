@@ -2,8 +2,8 @@
 // ("bf16 MFMA conv + fp32 memory"): bf16 NHWC activations and weights, fp32 accumulation in
 // v_mfma_f32_32x32x16_bf16, bf16 (or fp32 for the last layer) output rounded once on store.
 // Same decomposition as the fp32 kernel (mfma_f32.hip): 128 x {128,64} tile per 256-thread workgroup,
-// 4x4-pixel patch row order (pool in the epilogue), K order = 64-channel chunk outer / tap inner, one LDS
-// buffer at 3 workgroups per CU, XCD-aware tile order.  A K-tile is 64 bf16 = 128 B per row: the LDS image
+// 4x4-pixel patch row order (pool in the epilogue), K order = 64-channel chunk outer / tap inner, LDS-DMA
+// staging at 4 workgroups per CU, XCD-aware tile order.  A K-tile is 64 bf16 = 128 B per row: the LDS image
 // and the ds_read_b128 fragment addresses are byte-identical to the fp32 kernel's, one MFMA now consumes
 // what four fp32 MFMAs did.
 #include "common.h"
@@ -13,7 +13,6 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int BKB = 64;            // bf16 elements per K-tile (128 bytes)
-constexpr int LDB = 36;            // LDS row stride in 4-byte words (144 bytes), as the fp32 kernel
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -23,142 +22,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) {
     return u.b;
 }
 
-template <int BN>
-__device__ __forceinline__ void mma_ktile_bf16(const float* __restrict__ As, const float* __restrict__ Bs,
-                                               f32x16 (&acc)[2][BN / 64], int wm, int wn, int lane) {
-    constexpr int TN = BN / 64;
-    const int i = lane & 31, kh = lane >> 5;
-    const float* ap = As + (wm * 64 + i) * LDB + kh * 4;
-    const float* bp = Bs + (wn * (BN / 2) + i) * LDB + kh * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {          // four K=16 steps: lane half kh supplies k = 16q + 8kh .. +7
-        f32x4 a[2], b[TN];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(ap + tm * 32 * LDB + q * 8);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const f32x4*>(bp + tn * 32 * LDB + q * 8);
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[tm]), as_bf16x8(b[tn]), acc[tm][tn], 0, 0, 0);
-    }
-}
-
-template <int BN, bool POOL, bool OUTF32>
-__global__ __launch_bounds__(256, 3) void conv3x3_relu_bf16_kernel(
-    const __bf16* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
-    void* __restrict__ outv, int npatch, int H, int W, int Cin, int Cout, int Kp) {
-    constexpr int TN = BN / 64, NB = BN / 32;
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDB];
-    __shared__ int s_pix[BM], s_yx[BM], s_ppix[BM];
-
-    const int tid = threadIdx.x;
-    const int ctiles = Cout / BN;
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int rt = (li / ctiles) * 8 + xcd;
-    const int m0 = rt * BM;
-    const int n0 = (li % ctiles) * BN;
-    if (m0 >= npatch * 16) return;
-    if (tid < BM) {
-        ConvRowInfo ri = conv_row_info(m0 + tid, npatch, H, W);
-        s_pix[tid] = ri.pix; s_yx[tid] = ri.yx; s_ppix[tid] = ri.ppix;
-    }
-    __syncthreads();
-    const int lrow = tid >> 3, kg = tid & 7;
-    int rpix[4], ry[4], rx[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        rpix[s] = s_pix[lrow + 32 * s];
-        const int yx = s_yx[lrow + 32 * s];
-        ry[s] = yx >> 16; rx[s] = yx & 0xffff;
-    }
-    auto la = [&](int s, int kt) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int chunk = kt / 9, tap = kt - chunk * 9;
-        const int c0 = chunk * BKB;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int yy = ry[s] + dy, xx = rx[s] + dx;
-        if (rpix[s] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-            const size_t off = (size_t)(rpix[s] + dy * W + dx) * Cin + c0 + kg * 8;
-            v = *reinterpret_cast<const f32x4*>(in + off);
-        }
-        return v;
-    };
-    auto lb = [&](int s, int kt) -> f32x4 {
-        return *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + lrow + 32 * s) * Kp + kt * BKB + kg * 8);
-    };
-
-    f32x16 acc[2][TN];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    float* As = lds;
-    float* Bs = lds + BM * LDB;
-    const int nk = Kp / BKB;
-    f32x4 ra[4], rb[NB];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) ra[s] = la(s, 0);
-#pragma unroll
-    for (int s = 0; s < NB; ++s) rb[s] = lb(s, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(As + (lrow + 32 * s) * LDB + kg * 4) = ra[s];
-#pragma unroll
-        for (int s = 0; s < NB; ++s) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * s) * LDB + kg * 4) = rb[s];
-        __syncthreads();
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) ra[s] = la(s, kt + 1);
-#pragma unroll
-            for (int s = 0; s < NB; ++s) rb[s] = lb(s, kt + 1);
-        }
-        mma_ktile_bf16<BN>(As, Bs, acc, wm, wn, lane);
-        __syncthreads();
-    }
-
-    const int kh = lane >> 5, col = lane & 31;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn * (BN / 2) + tn * 32 + col;
-        const float bv = bias[n];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int mbase = wm * 64 + tm * 32 + 4 * kh;
-            if constexpr (!POOL) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pix = s_pix[mbase + (r & 3) + 8 * (r >> 2)];
-                    if (pix >= 0) {
-                        const float v = fmaxf(acc[tm][tn][r] + bv, 0.f);
-                        if constexpr (OUTF32) reinterpret_cast<float*>(outv)[(size_t)pix * Cout + n] = v;
-                        else reinterpret_cast<__bf16*>(outv)[(size_t)pix * Cout + n] = (__bf16)v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int pp = s_ppix[mbase + 8 * g];
-                    const float v = fmaxf(fmaxf(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1]),
-                                          fmaxf(acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
-                    if (pp >= 0) {
-                        const float o = fmaxf(v + bv, 0.f);
-                        if constexpr (OUTF32) reinterpret_cast<float*>(outv)[(size_t)pp * Cout + n] = o;
-                        else reinterpret_cast<__bf16*>(outv)[(size_t)pp * Cout + n] = (__bf16)o;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// LDS-DMA staged variant (the fp32 kernel's variant 4): rows are 128 B (64 bf16), chunk c of row r in slot
+// LDS-DMA staging (as the fp32 direct kernel): rows are 128 B (64 bf16), chunk c of row r in slot
 // c ^ ((r >> 1) & 7), one DMA wave-instruction fills 8 rows; no VGPR staging -> 4 workgroups per CU.
 __device__ __attribute__((aligned(128))) float g_zero_page_bf16[32];
 
@@ -304,40 +168,22 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __
     wp[idx] = (__bf16)w[(size_t)(tap * Cin + c) * Cout + n];
 }
 
-int g_bf16_dma = 1;   // 1: LDS-DMA staging (default), 0: VGPR staging
-
 template <int BN>
 void launch_bf16(const __bf16* in, const __bf16* wp, const float* bias, void* out, int npatch, int H, int W, int cin,
                  int cout, int pool, int out_f32, hipStream_t st) {
     const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
     dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
     const int Kp = 9 * cin;
-    if (g_bf16_dma) {
-        if (pool) {
-            if (out_f32) conv3x3_relu_bf16_dma_kernel<BN, true, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            else conv3x3_relu_bf16_dma_kernel<BN, true, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-        } else {
-            if (out_f32) conv3x3_relu_bf16_dma_kernel<BN, false, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            else conv3x3_relu_bf16_dma_kernel<BN, false, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-        }
-        return;
-    }
     if (pool) {
-        if (out_f32) conv3x3_relu_bf16_kernel<BN, true, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-        else conv3x3_relu_bf16_kernel<BN, true, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        if (out_f32) conv3x3_relu_bf16_dma_kernel<BN, true, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        else conv3x3_relu_bf16_dma_kernel<BN, true, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
     } else {
-        if (out_f32) conv3x3_relu_bf16_kernel<BN, false, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-        else conv3x3_relu_bf16_kernel<BN, false, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        if (out_f32) conv3x3_relu_bf16_dma_kernel<BN, false, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        else conv3x3_relu_bf16_dma_kernel<BN, false, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
     }
 }
 
 }  // namespace
-
-extern "C" int ntk_vgg_set_bf16_conv_variant(int v) {
-    NTK_REQUIRE(v == 0 || v == 1, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_bf16_conv_variant: %d", v);
-    g_bf16_dma = v;
-    return NTK_OK;
-}
 
 extern "C" int ntk_vgg_pack_weights_bf16(const float* w_hwio, void* w_packed_bf16, int cin, int cout, void* stream) {
     NTK_REQUIRE(w_hwio && w_packed_bf16, NTK_ERR_BAD_PTR, "ntk_vgg_pack_weights_bf16: null pointer");

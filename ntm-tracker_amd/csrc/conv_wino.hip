@@ -33,7 +33,6 @@ constexpr int KC = 16;             // channel granularity of the packed weights 
 //   4 x 4 x 2  all 32 rows, two 100-pixel patches (consecutive sub-blocks, possibly of different frames): tile grids
 //              that are multiples of 4 x 4 (conv3_x: 28 x 28 tiles)
 //   2 x 2 x 8  all 32 rows, eight 36-pixel patches: any even tile grid (conv4_x: 14 x 14 tiles); 1.6x the staging
-//   14 x 2 x 1 28 of the 32 rows, 180-pixel patch: tile grids that are multiples of 14 x 2 (kept as a tuning choice)
 constexpr int BNW = 64;            // output channels per workgroup
 
 
@@ -85,7 +84,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 // scalar base per iteration + immediates.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KC2 = 8, RSR2 = 12, RSV2 = 8;
-__device__ __attribute__((aligned(16))) float g_wino_zero[1024] = {0.f};     // padding pixels read zeros here; pointers advance with K (Cin <= 1024)
+constexpr int WINO_MAX_CIN = 1024;
+__device__ __attribute__((aligned(16))) float g_wino_zero[WINO_MAX_CIN] = {0.f};   // padding pixels read zeros here; pointers advance with K, so Cin <= WINO_MAX_CIN (checked by the entry point)
 
 template <bool POOL, int TW, int TH, int NSUB>
 __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
@@ -318,13 +318,6 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
 
 }  // namespace
 
-static int g_wino_small = 1;     // 1: 2x2x8 tile blocks where neither 8x4 nor 4x4x2 fits; 0: 14x2 blocks when W % 28 == 0
-extern "C" int ntk_vgg_set_wino_variant(int v) {
-    NTK_REQUIRE(v == 0 || v == 1, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_wino_variant: %d (0 or 1)", v);
-    g_wino_small = v;
-    return NTK_OK;
-}
-
 extern "C" size_t ntk_vgg_wino_packed_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
 extern "C" int ntk_vgg_pack_weights_wino(const float* w_hwio, float* u_packed, int cin, int cout, void* stream) {
@@ -343,19 +336,19 @@ extern "C" int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_pac
                 "ntk_vgg_conv3x3_relu_wino_f32: 16-byte alignment");
     NTK_REQUIRE(frames > 0 && H >= 4 && (H % 4) == 0 && W >= 4 && (W % 4) == 0, NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_wino_f32: frames=%d H=%d W=%d (H, W multiples of 4)", frames, H, W);
-    NTK_REQUIRE(cin >= KC && (cin % KC) == 0 && cout >= BNW && (cout % BNW) == 0, NTK_ERR_UNSUPPORTED,
-                "ntk_vgg_conv3x3_relu_wino_f32: cin=%d (multiple of 16) cout=%d (multiple of 64)", cin, cout);
+    NTK_REQUIRE(cin >= KC && (cin % KC) == 0 && cin <= WINO_MAX_CIN && cout >= BNW && (cout % BNW) == 0, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino_f32: cin=%d (multiple of 16, at most %d: the zero page padding pixels read from) "
+                "cout=%d (multiple of 64)", cin, WINO_MAX_CIN, cout);
     NTK_REQUIRE((unsigned long long)frames * H * W * cin < 0xffffffffull, NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_wino_f32: input of %d x %d x %d x %d floats exceeds the 32-bit offset range", frames, H, W, cin);
     WinoArgs a;
     a.in = in; a.U = u_packed; a.bias = bias; a.out = out;
     a.frames = frames; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
-    // tile-block shape (see the table at the top): 0 = 8x4x1, 1 = 4x4x2, 2 = 14x2x1, 3 = 2x2x8
+    // tile-block shape (see the table at the top): 0 = 8x4x1, 1 = 4x4x2, 3 = 2x2x8
     int shape = ((W % 16) == 0 && (H % 8) == 0) ? 0 : (((W % 8) == 0 && (H % 8) == 0) ? 1 : 3);
-    if (shape == 3 && g_wino_small == 0 && (W % 28) == 0) shape = 2;
     a.nCB = cout / BNW;
-    a.bxN = shape == 0 ? W / 16 : (shape == 1 ? W / 8 : (shape == 2 ? W / 28 : W / 4));
-    a.byN = shape == 2 || shape == 3 ? H / 4 : H / 8;
+    a.bxN = shape == 0 ? W / 16 : (shape == 1 ? W / 8 : W / 4);
+    a.byN = shape == 3 ? H / 4 : H / 8;
     const long long NQ = (long long)frames * a.byN * a.bxN;
     const long long NS = shape == 1 ? (NQ + 1) / 2 : (shape == 3 ? (NQ + 7) / 8 : NQ);
     NTK_REQUIRE(NS < (1ll << 30) && (a.nCB <= 8 ? (8 % a.nCB) == 0 : (a.nCB % 8) == 0), NTK_ERR_UNSUPPORTED,
@@ -372,10 +365,8 @@ extern "C" int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_pac
         if (fuse_pool) WINO_LAUNCH(true, 8, 4, 1); else WINO_LAUNCH(false, 8, 4, 1);
     } else if (shape == 1) {
         if (fuse_pool) WINO_LAUNCH(true, 4, 4, 2); else WINO_LAUNCH(false, 4, 4, 2);
-    } else if (shape == 3) {
-        if (fuse_pool) WINO_LAUNCH(true, 2, 2, 8); else WINO_LAUNCH(false, 2, 2, 8);
     } else {
-        if (fuse_pool) WINO_LAUNCH(true, 14, 2, 1); else WINO_LAUNCH(false, 14, 2, 1);
+        if (fuse_pool) WINO_LAUNCH(true, 2, 2, 8); else WINO_LAUNCH(false, 2, 2, 8);
     }
 #undef WINO_LAUNCH
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_wino_f32");

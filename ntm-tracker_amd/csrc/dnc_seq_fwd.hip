@@ -517,11 +517,11 @@ extern "C" int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hi
     dnc_fwd_lds(a.d, L);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
     NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED, "ntk_dnc_seq_fwd: needs %zu B of LDS (> 160 KiB)", lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dnc_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { ntk_set_error("ntk_dnc_seq_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
-        attr_set = true;
+    {
+        static NtkLdsAttrCache lds_cache;
+        const void* const ks[] = {(const void*)dnc_seq_fwd_kernel};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 1, "ntk_dnc_seq_fwd");
+        if (rc_lds != NTK_OK) return rc_lds;
     }
     dnc_seq_fwd_kernel<<<B, DT, lds_bytes, (hipStream_t)stream>>>(a, L);
     NTK_CHECK_LAUNCH("ntk_dnc_seq_fwd");

@@ -583,29 +583,18 @@ extern "C" int ntk_vgg_pack_weights(const float* w_hwio, float* w_packed, int ci
     return NTK_OK;
 }
 
-static int g_conv_variant = 4;   // tuning knob (ntk_vgg_set_conv_variant): 4 LDS-DMA staging (default), 2 VGPR staging; same results
-
 template <int BN, bool SMALLC>
 static void launch_conv(const float* in, const float* wp, const float* bias, float* out, int npatch,
                         int H, int W, int cin, int cout, int Kp, int pool, hipStream_t st) {
     const long rtiles = ((long)npatch * 16 + BM - 1) / BM;
     dim3 grid((unsigned)(((rtiles + 7) / 8) * 8 * (cout / BN)));
-    if constexpr (!SMALLC) {
-        if (g_conv_variant == 4) {
-            if (pool) conv3x3_relu_dma_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            else conv3x3_relu_dma_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-            return;
-        }
+    if constexpr (!SMALLC) {       // LDS-DMA staging, swizzled un-padded LDS image, 4 workgroups per CU
+        if (pool) conv3x3_relu_dma_kernel<BN, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        else conv3x3_relu_dma_kernel<BN, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+    } else {                       // tiny Cin: VGPR-staged kernel with the scalar-gather loader
+        if (pool) conv3x3_relu_kernel<BN, SMALLC, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
+        else conv3x3_relu_kernel<BN, SMALLC, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
     }
-    // VGPR-staged kernel: tiny Cin (scalar-gather loader) and variant 2
-    if (pool) conv3x3_relu_kernel<BN, SMALLC, true><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-    else conv3x3_relu_kernel<BN, SMALLC, false><<<grid, 256, 0, st>>>(in, wp, bias, out, npatch, H, W, cin, cout, Kp);
-}
-
-extern "C" int ntk_vgg_set_conv_variant(int v) {
-    NTK_REQUIRE(v == 2 || v == 4, NTK_ERR_BAD_SHAPE, "ntk_vgg_set_conv_variant: %d (2 or 4)", v);
-    g_conv_variant = v;
-    return NTK_OK;
 }
 
 namespace {
@@ -691,7 +680,7 @@ extern "C" int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, 
     const int Kp = ntk_vgg_packed_k(cin);
     hipStream_t st = (hipStream_t)stream;
     const bool bn128 = (cout % 128) == 0;
-    if (cin == 3 && cout == 64 && !fuse_pool && (W % 32) == 0 && g_conv_variant >= 4) {
+    if (cin == 3 && cout == 64 && !fuse_pool && (W % 32) == 0) {
         const long nseg = (long)frames * H * (W / 32);
         NTK_REQUIRE(nseg < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32: %ld row segments", nseg);
         const int wgs = (int)((nseg + 3) / 4 < 1024 ? (nseg + 3) / 4 : 1024);      // 256 CUs x 4 workgroups, waves stride over segments

@@ -534,15 +534,11 @@ extern "C" int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int h
     ntm_bwd_lds(a.d, T, ldkT, ldhT, L);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
     NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_bwd: needs %zu B of LDS (> 160 KiB)", lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ntm_seq_bwd_kernel<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { ntk_set_error("ntk_ntm_seq_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
-        attr_set = true;
+    {
+        static NtkLdsAttrCache lds_cache;
+        const void* const ks[] = {(const void*)ntm_seq_bwd_kernel<768, false>, (const void*)ntm_seq_bwd_kernel<1024, false>, (const void*)ntm_seq_bwd_kernel<768, true>};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 3, "ntk_ntm_seq_bwd");
+        if (rc_lds != NTK_OK) return rc_lds;
     }
     const bool fix = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2 &&
                       T == 640 && !write_first && ldkT == 280 && ldhT == 200);

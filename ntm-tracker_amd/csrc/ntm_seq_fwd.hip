@@ -374,6 +374,11 @@ int ntm_validate_dims(const NtmDims& d, const char* who) {
                     d.R * d.Md <= 1024,
                 NTK_ERR_UNSUPPORTED, "%s: hidden=%d heads=%d mem_dim=%d exceed one workgroup", who, d.hid, d.H, d.Md);
     NTK_REQUIRE(d.SS >= 1 && d.SS < d.N && d.O >= 1, NTK_ERR_BAD_SHAPE, "%s: shift space %d / output_dim %d", who, d.SS, d.O);
+    // limits of the kernels' fixed decomposition: shift taps live in a 5-element register array, addressing runs one
+    // WAVE per head, and the column norms of M need one wave beyond those of the hidden units
+    NTK_REQUIRE(d.SS <= 5, NTK_ERR_UNSUPPORTED, "%s: shift_range=%d (shift space %d > 5 taps)", who, (d.SS - 1) / 2, d.SS);
+    NTK_REQUIRE((d.H + 1) * 64 <= 1024, NTK_ERR_UNSUPPORTED, "%s: %d heads (one wave per head: at most 15)", who, d.H);
+    NTK_REQUIRE(((d.hid + 63) / 64 + 1) * 64 <= 1024, NTK_ERR_UNSUPPORTED, "%s: hidden=%d (at most 960)", who, d.hid);
     return NTK_OK;
 }
 
@@ -421,15 +426,11 @@ extern "C" int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int h
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
     NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED,
                 "ntk_ntm_seq_fwd: state needs %zu B of LDS (> 160 KiB)", lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ntm_seq_fwd_kernel<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { ntk_set_error("ntk_ntm_seq_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NTK_ERR_HIP; }
-        attr_set = true;
+    {
+        static NtkLdsAttrCache lds_cache;
+        const void* const ks[] = {(const void*)ntm_seq_fwd_kernel<768, false>, (const void*)ntm_seq_fwd_kernel<1024, false>, (const void*)ntm_seq_fwd_kernel<768, true>};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 3, "ntk_ntm_seq_fwd");
+        if (rc_lds != NTK_OK) return rc_lds;
     }
     const bool fix = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2 && T == 640);
     if (fix) ntm_seq_fwd_kernel<768, true><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);

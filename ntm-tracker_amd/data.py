@@ -18,50 +18,64 @@ import numpy as np
 import torch
 
 from . import _lib
+from .geometry import discrete_gauss
 
 VGG_MEAN = (123.68, 116.78, 103.94)
 
 
+SPLITS = ("train", "val")
+
+
+def _stems(seqdir, suffix=".txt"):
+    """Frame stems ('000000', ...) of one <seq>_<track> folder, in name order."""
+    return sorted(name[:-len(suffix)] for name in os.listdir(seqdir) if name.endswith(suffix))
+
+
 def get_valid_sequences(sequences_dir, min_length):
-    """direct_offset_output.py:94-120 (Python-2 integer division for the stride)."""
-    sequences = [os.path.join(sequences_dir, x) for x in sorted(os.listdir(sequences_dir))]
-    result, train, val = [], [], []
-    for seqdir in sequences:
-        files = sorted([x[:-4] for x in os.listdir(seqdir) if x.endswith('.txt')])
-        skip = len(files) // min_length
-        if skip == 0:
+    """Enumerate the format-(B) folders under `sequences_dir` that hold at least `min_length` frames.
+
+    Contract (behaviour of direct_offset_output.py:94-120): a folder with n >= min_length frame records is
+    subsampled with the integer stride n // min_length starting at its first frame, keeping exactly min_length
+    stems; shorter folders are dropped.  Returns (all, train, val), each a list of (folder, stems); the split is
+    decided by 'train' / 'val' appearing in the folder path ('train' is tested first), and a folder that names
+    neither is an error."""
+    everything = []
+    by_split = {name: [] for name in SPLITS}
+    for entry in sorted(os.listdir(sequences_dir)):
+        folder = os.path.join(sequences_dir, entry)
+        stems = _stems(folder)
+        stride = len(stems) // min_length
+        if stride < 1:
             continue
-        sliced = files[::skip][:min_length]
-        result.append((seqdir, sliced))
-        if 'train' in seqdir:
-            train.append((seqdir, sliced))
-        elif 'val' in seqdir:
-            val.append((seqdir, sliced))
-        else:
-            raise Exception('expect either train or val in sequence name')
-    return result, train, val
+        item = (folder, stems[0:(min_length - 1) * stride + 1:stride])
+        split = next((name for name in SPLITS if name in folder), None)
+        everything.append(item)
+        if split is None:
+            raise ValueError("sequence folder %r names neither of the splits %s" % (folder, "/".join(SPLITS)))
+        by_split[split].append(item)
+    return everything, by_split["train"], by_split["val"]
 
 
 def default_get_batch(index, batch_size, seq_length, seqs):
-    """direct_offset_output.py:122-142 (legacy pickle contract)."""
-    seq_batch = seqs[index:index + batch_size]
-    index += batch_size
-    frame_names, real_gts = [], []
-    for seq_dir, obj_name, subseq_id, seq_len, seq in seq_batch:
-        seq = seq[:seq_length]
-        frame_names += [x[0] for x in seq]
-        real_gts.append(np.array([np.reshape(x[-1][0], (-1)) for x in seq]))
-    return frame_names, np.array(real_gts), index
+    """Legacy pickle contract (A) (behaviour of direct_offset_output.py:122-142): `seqs` holds records
+    (seq_dir, obj_name, subseq_id, seq_len, frames) with frames = [(path, (w, h), bbox, [gt maps per layer])].
+    Takes records [index, index + batch_size), the first `seq_length` frames of each, and returns
+    (frame paths flattened [B*T], first-layer gt maps flattened to [B, T, F], index + batch_size)."""
+    stop = index + batch_size
+    names, gts = [], []
+    for record in seqs[index:stop]:
+        frames = record[4][:seq_length]
+        names.extend(frame[0] for frame in frames)
+        gts.append(np.array([np.asarray(frame[-1][0]).reshape(-1) for frame in frames]))
+    return names, np.array(gts), stop
 
 
 def sevenbyseven_get_batch(index, batch_size, seqs):
-    """direct_offset_output.py:144-157."""
-    seq_batch = seqs[index:index + batch_size]
-    index += batch_size
-    frame_names = []
-    for seq, frames in seq_batch:
-        frame_names += [os.path.join(seq, x) for x in frames]
-    return frame_names, index
+    """Format (B) batching (behaviour of direct_offset_output.py:144-157): `seqs` as returned by
+    get_valid_sequences; -> (frame paths without suffix [B*T], index + batch_size)."""
+    stop = index + batch_size
+    names = [os.path.join(folder, stem) for folder, stems in seqs[index:stop] for stem in stems]
+    return names, stop
 
 
 def load_frame_record(path_nosuffix, gt_width=8):
@@ -136,10 +150,7 @@ class SyntheticSequences(object):
         for i in range(0, B * T, 64):
             n = min(64, B * T - i)
             frames[i:i + n] = torch.rand((n, 224, 224, 3), generator=g) * 255.0 - mean
-        y, x = np.ogrid[-3.5:4.5, -3.5:4.5]
-        hm = np.exp(-(x * x + y * y) / 2.0)
-        hm[hm < np.finfo(hm.dtype).eps * hm.max()] = 0
-        hm /= hm.sum()
+        hm = discrete_gauss((.5, .5), (8, 8), 1.0)
         gts = torch.from_numpy(np.tile(hm.astype(np.float32)[None], (B * T, 1, 1)))
         offs = torch.rand((B, T, 2), generator=g) - 0.5
         offs[:, 0, :] = 0

@@ -33,6 +33,7 @@ class FlatParams(object):
 
     def __init__(self, shapes, device):
         n = 0
+        self.shapes = list(shapes)
         self.offsets = {}
         for name, shp in shapes:
             sz = 1
@@ -119,7 +120,9 @@ class DNC(object):
         Wy[self.Ky, :self.O] = t(sd["output_linear/b"])
         # flat fp32 master copy (kernel layout) + same-shaped gradient: the optimiser and the all-reduce are flat passes
         shapes = [("WxT", WxT), ("Wr", Wr), ("Wi", Wi), ("Wy", Wy)]
-        self.params = FlatParams([(n, tuple(v.shape)) for n, v in shapes], dev)
+        layout = [(n, tuple(v.shape)) for n, v in shapes]
+        if getattr(self, "params", None) is None or self.params.shapes != layout:
+            self.params = FlatParams(layout, dev)       # else: load into the existing buffer (an optimiser may hold it)
         for n, v in shapes:
             self.params.view(n).copy_(v.to(dev))
 

@@ -56,10 +56,9 @@ class PackedParams(object):
     """Flat fp32 master copy of the trainable parameters in kernel layout
     (see csrc/ntm_common.h) with named views, plus a same-shaped gradient."""
 
-    def __init__(self, dims, device):
-        d = dims
-        self.dims = d
-        self.shapes = [
+    @staticmethod
+    def shapes_for(d):
+        return [
             ("WxT", (4 * d.hid, d.ldx)),
             ("Wr", (d.ldz, 4 * d.hid)),
             ("Wa", (d.ldh, d.PP)),
@@ -67,6 +66,11 @@ class PackedParams(object):
             ("V_w", (d.H, d.N)),
             ("V_r", (d.R, d.Md)),
         ]
+
+    def __init__(self, dims, device):
+        d = dims
+        self.dims = d
+        self.shapes = self.shapes_for(d)
         n = 0
         self.offsets = {}
         for name, shp in self.shapes:
@@ -207,7 +211,12 @@ class NTMCell(object):
     def _build(self, input_dim, tf_state_dict=None):
         self.dims = NTMDims(input_dim, self.output_dim, self.mem_size, self.mem_dim, self.shift_range,
                             self.controller_hidden_size, self.read_head_size, self.write_head_size)
-        self.params = PackedParams(self.dims, self.device)
+        if self.params is not None and self.params.shapes == PackedParams.shapes_for(self.dims):
+            # same layout: load INTO the existing flat buffer, so views, gradient buffer and any optimiser bound to
+            # this PackedParams (tracker.RMSPropClip holds flat / grad / ms / mom by reference) stay valid
+            self.params.dims = self.dims
+        else:
+            self.params = PackedParams(self.dims, self.device)
         if tf_state_dict is None:
             d = self.dims
             g = torch.Generator().manual_seed(0 if self.seed is None else int(self.seed))

@@ -6,7 +6,7 @@ pass, one serialise kernel and ONE 65-step sequence-kernel launch with the state
 
 Quirk Q8 is kept: inference puts the delimiter row FIRST and reads the output of the LAST feature step
 (:400-404, :274-282), although training puts it last and reads the delimiter step.
-Geometry helpers restate preprocess.py:73-149, :205-240 (pure host scalar math).
+Box geometry (preprocess.py:73-149, :205-240 for behaviour) lives in ntmtrack.geometry.
 """
 import collections
 
@@ -23,57 +23,9 @@ Rectangle = collections.namedtuple("Rectangle", ["x", "y", "width", "height"])  
 VGG_MEAN = (123.68, 116.78, 103.94)
 
 
-# ---- preprocess.py geometry (host side)
-def normalize_bbox(size, bbox):
-    width, height = size
-    y1, x1, y2, x2 = bbox
-    return [y1 / float(height - 1), x1 / float(width - 1), y2 / float(height - 1), x2 / float(width - 1)]
-
-
-def calculate_cropbox(normalbbox, cropbox_grid, bbox_grid):
-    y1, x1, y2, x2 = normalbbox
-    ratio = cropbox_grid / float(bbox_grid)
-    xc, cw = (x1 + x2) / 2, ratio * (x2 - x1)
-    yc, ch = (y1 + y2) / 2, ratio * (y2 - y1)
-    return [yc - ch / 2, xc - cw / 2, yc + ch / 2, xc + cw / 2]
-
-
-def calculate_transformation(cropbox):
-    y1, x1, y2, x2 = cropbox
-    w, h = x2 - x1, y2 - y1
-    return np.array([[1 / w, 0, -x1 / w], [0, 1 / h, -y1 / h], [0, 0, 1]])
-
-
-def apply_transformation(normalbbox, transformation):
-    y1, x1, y2, x2 = normalbbox
-    p1 = transformation @ np.array([x1, y1, 1.0])
-    p2 = transformation @ np.array([x2, y2, 1.0])
-    return [p1[1], p1[0], p2[1], p2[0]]
-
-
-def offset_bbox(init_bbox, offsets):
-    dy, dx = offsets
-    y1, x1, y2, x2 = init_bbox
-    return (y1 + dy, x1 + dx, y2 + dy, x2 + dx)
-
-
-def discrete_gauss(center=(.5, .5), shape=(8, 8), sigma=1.0):
-    cx, cy = [a * b for a, b in zip(center, shape)]
-    w, h = shape
-    y, x = np.ogrid[-cy + .5:h - cy + .5, -cx + .5:w - cx + .5]
-    hm = np.exp(-(x * x + y * y) / (2. * sigma * sigma))
-    hm[hm < np.finfo(hm.dtype).eps * hm.max()] = 0
-    s = hm.sum()
-    if s != 0:
-        hm /= s
-    return hm
-
-
-def generate_gt(normalbbox, cropbox_grid, bbox_grid, focus=3):
-    """preprocess.py:229-240.  sigma = bbox_grid / focus under the reference's Python-2 integer division."""
-    y1, x1, y2, x2 = normalbbox
-    sigma = bbox_grid // focus if isinstance(bbox_grid, int) and isinstance(focus, int) else bbox_grid / focus
-    return discrete_gauss(((x1 + x2) / 2., (y1 + y2) / 2.), (cropbox_grid, cropbox_grid), sigma)
+# ---- box geometry lives in ntmtrack.geometry (one implementation); re-exported here for callers of this module
+from .geometry import (normalize_bbox, calculate_cropbox, calculate_transformation, apply_transformation,   # noqa: E402,F401
+                       offset_bbox, discrete_gauss, generate_gt)
 
 
 def crop_and_resize(image, box, crop=224, mean=VGG_MEAN, out=None):

@@ -77,6 +77,28 @@ class _Checkpointing(object):
     def _ckpt_params(self):
         raise NotImplementedError
 
+    def _core(self):
+        raise NotImplementedError
+
+    def load_state_dict(self, sd, reset_optimizer=True):
+        """Import parameters under the reference's variable names into the tracker.  The core
+        loads into its existing flat buffer when the layout is unchanged; if it had to re-allocate, the optimiser
+        is re-bound to the new buffer.  Slots (ms = 1, mom = 0) and global_step restart unless reset_optimizer=False
+        and the buffer was kept."""
+        core = self._core()
+        before = core.params
+        core.load_state_dict(sd)
+        if core.params is not before:
+            o = self.opt
+            self.opt = RMSPropClip(core.params, o.lr, o.decay, o.momentum, o.eps, o.clip)
+        elif reset_optimizer:
+            self.opt.ms.fill_(1.0)
+            self.opt.mom.zero_()
+            self.opt.global_step = 0
+
+    def state_dict(self):
+        return self._core().state_dict()
+
     def save_checkpoint(self, path):
         P = self._ckpt_params()
         torch.save({"format": "ntmtrack-ckpt-1", "kind": type(self).__name__, "numel": P.numel,
@@ -224,6 +246,9 @@ class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def _ckpt_params(self):
         return self.cell.params
 
+    def _core(self):
+        return self.cell
+
     def train_step(self, frames, gts0, offsets):
         """VGG forward, NTM forward + BPTT, gradient all-reduce (if distributed), clip + RMSProp.
         Returns the (local) loss as a 1-element device tensor."""
@@ -260,6 +285,9 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
 
     def _ckpt_params(self):
         return self.core.params
+
+    def _core(self):
+        return self.core
 
     def forward_features(self, fmap, gts0, record=False):
         """-> logits [B,S,2] (batch-major view of the time-major core output, _with_dnc.py:534-541)."""

@@ -9,6 +9,7 @@ stands in for (parity unpinned): pow's gradient w.r.t. the
 exponent uses log(x) -> 0 for x <= 0; l2_normalize differentiates through
 rsqrt(max(sum x^2, eps)).
 """
+import numpy as np
 import torch
 
 from . import ntm_oracle as O
@@ -156,3 +157,24 @@ def vgg16_conv43(frames, weights):
             if pool:
                 x = torch.nn.functional.max_pool2d(x, 2, 2)
     return x.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def vgg16_conv43_bf16(frames, weights):
+    """The bf16 trunk of BASELINE config 5 restated on torch-CPU float64 convolutions, so that a 224x224 frame
+    finishes in seconds (oracle/ntm_oracle.py:vgg16_conv43_bf16 is the numpy restatement of the same thing and
+    tests/test_oracle_ntm.py holds the two together): conv1_1 multiplies the fp32 frames by fp32 weights; every
+    later layer multiplies bf16-rounded activations by bf16-rounded weights (exact products in float64), adds the
+    fp32 bias, ReLU (+ pool) and rounds the stored activation to bf16 -- except conv4_3, which stays fp32."""
+    x = torch.as_tensor(np.asarray(frames, dtype=np.float32)).double().permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for name, _cin, _cout, pool in O.VGG_LAYERS:
+            w, b = weights[name]
+            wq = np.asarray(w, np.float32) if name == "conv1_1" else O.bf16_round(np.asarray(w, np.float32))
+            wt = torch.as_tensor(wq).double().permute(3, 2, 0, 1).contiguous()
+            y = torch.relu(torch.nn.functional.conv2d(x, wt, torch.as_tensor(np.asarray(b, np.float32)).double(), padding=1))
+            if name == "conv4_3":
+                return y.permute(0, 2, 3, 1).contiguous().float().numpy()
+            if pool:
+                y = torch.nn.functional.max_pool2d(y, 2, 2)
+            x = torch.as_tensor(O.bf16_round(y.float().numpy())).double()
+    raise AssertionError("conv4_3 not reached")

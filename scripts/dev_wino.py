@@ -10,7 +10,7 @@ import os
 from ntmtrack import _lib
 dev = torch.device("cuda")
 rng = np.random.default_rng(0)
-_lib.lib().ntk_vgg_set_wino_variant(int(os.environ.get("WINO_VARIANT", "1")))
+
 
 
 def check(F, H, W, cin, cout, pool):

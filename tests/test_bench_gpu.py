@@ -34,5 +34,7 @@ def test_bench_emits_contract_json(cuda, capsys, monkeypatch):
         assert key in r, key
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.0 < r["frac"] <= 1.0, "roofline.frac is executed MFMA flops / peak: a utilisation"
+    assert r["algorithmic_tflops"] >= r["achieved"]
     # frames/s = frames per step / seconds per step
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2

@@ -269,3 +269,47 @@ def test_dnc_offset_tracker_training_step(cuda):
         step = np.max(np.abs(ref_new - sd[k]))
         err = np.max(np.abs(new[k].numpy().astype(np.float64) - ref_new))
         assert err <= 6e-8 + 5e-3 * step, (k, err, step)
+
+
+def test_dnc_full_length_bptt_gradients_match_autograd_oracle(cuda):
+    """BASELINE config 3's cell (DNC 256x64, 4 read heads, hidden 200, clip 20) over S = 650 strictly sequential
+    steps (10 serialised frames) of the tracking task, B = 1: loss and every gradient tensor against the float64
+    torch-autograd restatement (direct_offset_output_with_dnc.py:534-541, :615-620).  Per-tensor error printed."""
+    from oracle import ntm_oracle as O
+    from oracle import ntm_oracle_torch as OT
+    from oracle import dnc_oracle_torch as DT
+    from ntmtrack import dnc as G
+    from ntmtrack import tracker
+    B, T = 1, 10
+    S = T * 65
+    cfg = D.DNCConfig(514, 2, memory_size=256, word_size=64, num_reads=4, num_writes=1, hidden_size=200, clip_value=20)
+    rng = np.random.default_rng(23)
+    p = D.init_params(cfg, rng)
+    feats = np.maximum(rng.standard_normal((B, T, 64, 512)), 0).astype(np.float32)
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    x = O.serialize_inputs(feats, gts)                                  # [B,S,514]
+    offs = rng.uniform(-.5, .5, size=(B, T, 2)).astype(np.float32)
+    t64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
+    pt = {k: t64(v).requires_grad_(True) for k, v in p.items()}
+    ys, _ = DT.run_model(cfg, pt, t64(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))))
+    loss_ref, _ = OT.offset_loss(ys.permute(1, 0, 2), t64(offs))
+    loss_ref.backward()
+
+    core = G.DNC({"memory_size": 256, "word_size": 64, "num_reads": 4, "num_writes": 1}, {"hidden_size": 200}, 2, 20, device=cuda)
+    core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    out, _st = core.run_sequence(torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).to(cuda), None, record=True)
+    assert out.shape == (S, B, 2)
+    logits = out.transpose(0, 1).contiguous()
+    np.testing.assert_allclose(logits.cpu().numpy(), ys.permute(1, 0, 2).detach().numpy(), atol=1e-4)
+    loss, _pred, dlogits = tracker.offset_loss(logits, torch.from_numpy(offs).to(cuda), T)
+    grads = core.backward_sequence(core.last_X, dlogits)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), float(loss_ref.detach()), rtol=1e-4)
+    worst = {}
+    for k in sorted(p):
+        ref = pt[k].grad.numpy()
+        worst[k] = float(np.max(np.abs(grads[k].cpu().numpy() - ref)) / (np.max(np.abs(ref)) + 1e-30))
+    print("full-length (S=650) DNC gradient error vs float64 autograd, max|d|/max|ref| per tensor:")
+    for k, v in worst.items():
+        print("  %-36s %.3e" % (k, v))
+    assert max(worst.values()) < 3e-3, worst

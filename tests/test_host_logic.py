@@ -58,3 +58,24 @@ def test_shard_range_partitions_sequences():
         assert False
     except ValueError:
         pass
+
+
+def test_geometry_known_answers_of_the_reference():
+    """The reference's own self-tests for the box helpers (preprocess.py:152-157 calculate_transformation_test,
+    :223-226 discrete_gauss_test against the MATLAB-style fspecial of :195-204), restated on ntmtrack.geometry."""
+    from ntmtrack import geometry as G
+    box = [.3, .4, .5, .6]
+    np.testing.assert_almost_equal(G.apply_transformation(box, G.calculate_transformation(box)), [0, 0, 1, 1])
+    # fspecial('gaussian', (7,7), 0.75): centred grid -3..3
+    y, x = np.ogrid[-3:4, -3:4]
+    h = np.exp(-(x * x + y * y) / (2. * 0.75 * 0.75))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    h /= h.sum()
+    np.testing.assert_almost_equal(G.discrete_gauss((.5, .5), (7, 7), 0.75), h)
+    # the oracle's independent restatement agrees, also off-centre
+    np.testing.assert_allclose(G.discrete_gauss((.3, .6), (8, 8), 1.5), O.discrete_gauss((.3, .6), (8, 8), 1.5), rtol=1e-12)
+    assert G.normalize_bbox((641, 481), (48, 64, 96, 128)) == [0.1, 0.1, 0.2, 0.2]
+    np.testing.assert_allclose(G.calculate_cropbox([.4, .4, .6, .6], 8, 6), [.5 - .4 / 3, .5 - .4 / 3, .5 + .4 / 3, .5 + .4 / 3])
+    assert G.offset_bbox((.1, .2, .3, .4), (.5, -.1)) == (.6, .1, .8, .30000000000000004)
+    assert G.generate_gt([.25, .25, .75, .75], 8, 6, 4).shape == (8, 8)      # sigma = 6 // 4 = 1 (Python-2 division)
+    np.testing.assert_allclose(G.generate_gt([.25, .25, .75, .75], 8, 6, 4), G.discrete_gauss((.5, .5), (8, 8), 1))

@@ -126,6 +126,14 @@ def test_unsupported_configs_fail_loudly(cuda):
     with pytest.raises(NtkError):                                   # mem_size must be a multiple of 64
         st = cell.zero_state(1)
         cell(torch.zeros((1, 8), device=cuda), st)
+    # limits of the fused kernel's decomposition are refused, never computed wrongly: shift_range 3
+    # (7 taps > the 5-tap register array), 16 heads (one wave per head), hidden 1000 (> 960)
+    for kw in (dict(shift_range=3, write_head_size=1, read_head_size=1, controller_hidden_size=64),
+               dict(shift_range=1, write_head_size=8, read_head_size=8, controller_hidden_size=64, mem_dim=4),
+               dict(shift_range=1, write_head_size=1, read_head_size=1, controller_hidden_size=1000)):
+        c = NTMCell(2, mem_size=64, mem_dim=kw.pop("mem_dim", 8), controller_num_layers=1, input_dim=8, device=cuda, **kw)
+        with pytest.raises(NtkError):
+            c(torch.zeros((1, 8), device=cuda), c.zero_state(1))
 
 
 def test_full_length_sequence_drift(cuda):

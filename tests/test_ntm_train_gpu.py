@@ -114,8 +114,10 @@ def test_train_step_matches_oracle_update(cuda):
         new_ref[k] = pnew
 
     trk = tracker.NTMOffsetTracker(B, T, vgg_weights=None, device=cuda)
+    flat_before = trk.cell.params.flat
+    # the documented way to import reference weights; the optimiser built in __init__ must stay bound
     trk.cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, input_dim=D)
-    trk.opt = tracker.RMSPropClip(trk.cell.params)
+    assert trk.cell.params.flat is flat_before and trk.opt.p is trk.cell.params
     # feed the features through a fake conv4_3 map so the gather kernel is on the path too
     fmap = np.zeros((B * T, 28, 28, 512), np.float32)
     for i, (y, xx) in enumerate(O.CONV43_POINTS):
@@ -158,3 +160,71 @@ def test_checkpoint_roundtrip_resumes_bit_identically(cuda, tmp_path):
     d = tracker.DNCOffsetTracker(B, T, vgg_weights=None, mem_size=32, mem_dim=16, hidden_size=32, device=cuda)
     with pytest.raises(Exception):
         d.load_checkpoint(path)                      # wrong tracker kind is refused
+
+
+def test_load_state_dict_keeps_the_optimiser_bound(cuda):
+    """After tracker.load_state_dict / cell.load_state_dict the model must still train: the optimiser updates the
+    buffer the kernels read (same layout -> same buffer; different layout -> the tracker re-binds)."""
+    from ntmtrack import tracker
+    B, T = 2, 2
+    g = torch.Generator().manual_seed(5)
+    fmap = torch.relu(torch.randn((B * T, 28, 28, 512), generator=g)).to(cuda)
+    gts0 = torch.rand((B, 64), generator=g).to(cuda)
+    offs = (torch.rand((B, T, 2), generator=g) - 0.5).to(cuda)
+    src = tracker.NTMOffsetTracker(B, T, vgg_weights=None, device=cuda, seed=7)
+    for trk in (tracker.NTMOffsetTracker(B, T, vgg_weights=None, device=cuda, seed=1, learning_rate=1e-2),
+                tracker.DNCOffsetTracker(B, T, vgg_weights=None, mem_size=32, mem_dim=16, hidden_size=32, device=cuda,
+                                         learning_rate=1e-2)):
+        sd = (src if isinstance(trk, tracker.NTMOffsetTracker) else trk).state_dict()
+        sd = {k: v + 0.01 for k, v in sd.items()}
+        trk.load_state_dict(sd)
+        core = trk._core()
+        assert trk.opt.p is core.params
+        before = core.params.flat.clone()
+        trk.loss_and_grads(fmap, gts0, offs)
+        trk.opt.step()
+        torch.cuda.synchronize()
+        assert float((core.params.flat - before).abs().max()) > 0, "parameters did not move after load_state_dict"
+        got = trk.state_dict()
+        assert any(float((got[k] - sd[k]).abs().max()) > 0 for k in sd)
+
+
+def test_full_length_bptt_gradients_match_autograd_oracle(cuda):
+    """BASELINE config 2's full horizon: T = 20 frames -> S = 1300 strictly sequential steps of BPTT, B = 2, gradients
+    of every tensor against the float64 torch-autograd restatement (direct_offset_output.py:611-621).  The bound is
+    what fp32 storage + fp32 accumulation over 1300 dependent steps gives against float64, printed per tensor."""
+    from ntmtrack.ntm import NTMCell
+    from ntmtrack import tracker
+    name, kw, D, _T, _B, scale = GRAD_CASES[0]
+    T, B = 20, 2
+    cfg = O.NTMConfig(D, 2, **kw)
+    rng = np.random.default_rng(77)
+    params = O.init_params(cfg, rng, scale=scale)
+    for k in params:
+        if k.endswith("biases"):
+            params[k] = rng.uniform(-scale, scale, size=params[k].shape).astype(np.float32)
+    feats = np.maximum(rng.standard_normal((B, T, 64, 512)), 0).astype(np.float32)
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    x = O.serialize_inputs(feats, gts)
+    offs = rng.uniform(-0.5, 0.5, size=(B, T, 2)).astype(np.float32)
+    loss_ref, grads_ref, logits_ref, _ = OT.loss_and_grads(cfg, params, x, offs)
+
+    cell = NTMCell(2, mem_size=cfg.mem_size, mem_dim=cfg.mem_dim, shift_range=cfg.shift_range,
+                   controller_hidden_size=cfg.hidden, controller_num_layers=1, write_head_size=cfg.write_heads,
+                   read_head_size=cfg.read_heads, write_first=cfg.write_first, device=cuda)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, input_dim=D)
+    X = cell._pad_inputs(torch.from_numpy(x).to(cuda))
+    st0 = cell.zero_state(B)
+    logits, _o, _new, rec = cell.run_sequence(X, st0, record=True)
+    assert logits.shape == (B, 1300, 2)
+    loss, pred, dlogits = tracker.offset_loss(logits, torch.from_numpy(offs).to(cuda), T)
+    g0 = cell.backward_sequence(X, st0, rec, dlogits)
+    cell.init_state_backward(g0, B)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-4)
+    got = cell.params.to_tf(grad=True)
+    worst = {k: _relerr(got[k].numpy(), grads_ref[k]) for k in sorted(grads_ref)}
+    print("full-length (S=1300) NTM gradient error vs float64 autograd, max|d|/max|ref| per tensor:")
+    for k, v in worst.items():
+        print("  %-24s %.3e" % (k, v))
+    assert max(worst.values()) < 1e-3, worst

@@ -164,6 +164,19 @@ def test_vgg_numpy_vs_torch_conv_restatement():
     np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-3 * np.abs(a).max())
 
 
+def test_vgg_bf16_numpy_vs_torch_restatement():
+    """The two restatements of config 5's bf16 trunk (numpy, torch float64 conv2d) agree: the torch one is what the
+    GPU test uses at 224x224, where the numpy one would take minutes."""
+    rng = np.random.default_rng(4)
+    ws = O.init_vgg_weights(rng)
+    frame = (rng.uniform(0, 255, size=(1, 16, 16, 3)).astype(np.float32) - O.VGG_MEAN)
+    a = O.vgg16_conv43_bf16(frame, ws)
+    b = OT.vgg16_conv43_bf16(frame, ws)
+    # identical bf16 roundings except where a float64 sum lands within an ulp of a rounding boundary
+    assert np.max(np.abs(a - b)) <= 2e-2 * np.abs(a).max()
+    assert np.mean(np.abs(a - b)) <= 1e-4 * np.abs(a).max()
+
+
 # ---- golden vectors (regression freeze of the oracle; generated by tests/golden/make_golden.py)
 def test_golden_ntm_seq_small():
     g = np.load(os.path.join(GOLD, "ntm_seq_small.npz"))

@@ -174,3 +174,42 @@ def test_vgg_trunk_winograd_equals_direct_fullsize(cuda):
     assert len(a.packed_wino) == 9 and not d.packed_wino
     ya, yd = a(frames).cpu().numpy(), d(frames).cpu().numpy()
     assert _rel(ya, yd) < 1e-5
+
+
+def test_vgg_trunk_fullsize_matches_float64_oracle(cuda):
+    """One 224x224 frame (plus a second, so frame strides are exercised) through the DEFAULT trunk (conv1_1 direct +
+    nine fused Winograd layers: the 8x4x1 tile path at W = 224/112, 4x4x2 at 56, 2x2x8 at 28) and through the
+    all-direct trunk, against a float64 convolution oracle (torch-CPU conv2d in double: the second restatement of
+    direct_offset_output.py:417-422 / vgg.py:155-161).  north_star tolerance: 1e-4 of the activation scale."""
+    from ntmtrack import vgg
+    from oracle import ntm_oracle_torch as OT
+    rng = np.random.default_rng(11)
+    ws = O.init_vgg_weights(rng)
+    for k in ws:                                       # non-zero biases: the epilogue's bias add is on the path
+        ws[k] = (ws[k][0], (rng.standard_normal(ws[k][1].shape) * 0.05).astype(np.float32))
+    frames = (rng.uniform(0, 255, size=(2, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)
+    ref = OT.vgg16_conv43(frames.astype(np.float64), {k: (w.astype(np.float64), b.astype(np.float64)) for k, (w, b) in ws.items()})
+    assert ref.dtype == np.float64 and ref.shape == (2, 28, 28, 512)
+    x = torch.from_numpy(frames).to(cuda)
+    for algo, bound in (("winograd", 1e-5), ("direct", 1e-5)):
+        got = vgg.VGG16Conv43(ws, device=cuda, algo=algo)(x).cpu().numpy()
+        err = _rel(got, ref)
+        print("fp32 %s trunk at 224x224 vs float64: max error / max |ref| = %.3e" % (algo, err))
+        assert err < bound, (algo, err)
+
+
+def test_vgg_trunk_bf16_fullsize_matches_bf16_oracle(cuda):
+    """Config 5's bf16 trunk on a 224x224 frame vs the bf16-emulating oracle (same roundings, float64 sums)."""
+    from ntmtrack import vgg
+    from oracle import ntm_oracle_torch as OT
+    rng = np.random.default_rng(12)
+    ws = O.init_vgg_weights(rng)
+    frames = (rng.uniform(0, 255, size=(1, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)
+    ref = OT.vgg16_conv43_bf16(frames, ws)
+    ref32 = OT.vgg16_conv43(frames.astype(np.float64), {k: (w.astype(np.float64), b.astype(np.float64)) for k, (w, b) in ws.items()})
+    got = vgg.VGG16Conv43(ws, device=cuda, dtype="bf16")(torch.from_numpy(frames).to(cuda)).cpu().numpy()
+    scale = np.max(np.abs(ref))
+    e_max, e_mean = np.max(np.abs(got - ref)) / scale, np.mean(np.abs(got - ref)) / scale
+    print("bf16 trunk at 224x224 vs bf16 oracle: max %.3e mean %.3e; vs fp64 trunk: %.3e" % (e_max, e_mean, _rel(got, ref32)))
+    assert e_max < 2e-2 and e_mean < 1e-3
+    assert _rel(got, ref32) < 3e-2
