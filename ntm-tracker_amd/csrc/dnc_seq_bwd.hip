@@ -17,6 +17,13 @@
 // gradients are reproducible to rounding, not bitwise).
 #include "dnc_common.h"
 
+// The allocation gradient re-derives the usage ORDER of the forward pass from the recorded usages.  The forward
+// kernel evaluates nonusage = 1 - (eps + (1 - eps) u) op by op (no fused multiply-add); with contraction on, this
+// file's fma rounds differently in the last bit, two almost-tied slots can swap order between forward and backward,
+// and the usage / free-gate gradients come out wrong by orders of magnitude (found by the per-step gradient probe
+// scripts/dev_dnc_stepgrad.py: free_gate 1e-7 -> 8.7e-15 absolute error once the rounding matches).
+#pragma clang fp contract(off)
+
 struct DncBwdArgs {
     DncDims d;
     const float* WrT; int ldkT;      // [4*hid][ldkT]
