@@ -223,6 +223,27 @@ int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, f
                     float* rec_cr, float* rec_al, float* rec_p, float* rec_fwd, float* rec_bwd,
                     float* rec_M, float* rec_L, float* rec_ypre, void* stream);
 
+/* The same sequence kernel in CLUSTER form: k workgroups (one per CU) cooperate on each sequence -- the link rows and
+ * the controller's hidden units are split k ways, the per-slot state and the N x W memory are replicated in LDS, and
+ * two small exchanges per step go through a mailbox in `workspace` (csrc/dnc_cluster.h).  Same arguments, same state
+ * in-place semantics and same records as ntk_dnc_seq_fwd; results differ from it by summation order only.
+ * ntk_dnc_cluster_plan: the cluster size for a shape (k_request 0 = the largest that fits: B * k <= 256 CUs, link
+ * rows + memory LDS resident; NTK_ERR_UNSUPPORTED and *k = 0 when the shape is outside the cluster kernels' range:
+ * num_writes != 1, memory_size not a multiple of 64, ...) and the workspace size in bytes.  The workspace is
+ * caller-owned device memory, 16-byte aligned, private to one launch at a time; its control words are re-zeroed by
+ * every launch.  ntk_dnc_cluster_status synchronises `stream` and reports whether a hand-off of the last launch on
+ * that workspace timed out (every in-kernel spin is bounded; a launch that could not make progress aborts itself). */
+int ntk_dnc_cluster_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes);
+int ntk_dnc_cluster_status(const void* workspace, int B, int k, void* stream);
+int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value, int k,
+                        const float* xproj, const float* Wr, const float* Wi, const float* Wy,
+                        float* mem, float* link, float* usage, float* rw, float* ww, float* prec,
+                        float* reads, float* hc, float* out,
+                        float* rec_z, float* rec_gates, float* rec_c, float* rec_hc, float* rec_yin,
+                        float* rec_ifc, float* rec_u, float* rec_ww, float* rec_rw, float* rec_cw,
+                        float* rec_cr, float* rec_al, float* rec_p, float* rec_fwd, float* rec_bwd,
+                        float* rec_M, float* rec_L, float* rec_ypre, void* workspace, void* stream);
+
 /* Stand-alone DNC addressing modules (dnc/addressing.py), the module-level API the reference's own tests call:
  * CosineWeights._build (:83-105), TemporalLinkage._build (:133-153) and directional_read_weights (:155-181),
  * Freeness._build (:279-305) and write_allocation_weights (:307-340; one head: _allocation :376-405). */

@@ -39,6 +39,9 @@ def _sig(lib):
         "ntk_ntm_seq_bwd": (c_int, [c_int] * 10 + [P, c_int, P, c_int] + [P] * 21 + [P]),
         "ntk_dnc_padded_dims": (c_int, [c_int] * 6 + [ctypes.POINTER(c_int)] * 8),
         "ntk_dnc_seq_fwd": (c_int, [c_int] * 8 + [ctypes.c_float] + [P] * 13 + [P] * 18 + [P]),
+        "ntk_dnc_cluster_plan": (c_int, [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
+        "ntk_dnc_cluster_status": (c_int, [P, c_int, c_int, P]),
+        "ntk_dnc_cluster_fwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P] * 13 + [P] * 18 + [P, P]),
         "ntk_dnc_cosine_weights": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_dnc_linkage": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
         "ntk_dnc_directional_read_weights": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

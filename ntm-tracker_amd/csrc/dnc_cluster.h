@@ -1,0 +1,119 @@
+// Shared pieces of the DNC CLUSTER kernels (dnc_cluster_fwd.hip / dnc_cluster_bwd.hip): k workgroups, one per CU,
+// cooperate on ONE sequence.  Each workgroup owns N/k rows of the N x N temporal link (LDS resident) and 1/k of the
+// controller's hidden units; everything per-slot (usage, weights, the N x W memory) is replicated and computed
+// redundantly from bit-identical inputs, so the replicas never diverge.  What must cross workgroups does so through
+// a per-sequence mailbox in global memory, twice per step in each direction.
+//
+// Hand-off protocol (MI355X_MICROARCH.md "Valid forms", first row; cdna_hip_programming.md Guideline 16, R1):
+//   producer  every payload store is an agent-scope relaxed atomic store (global_store ... sc1: write-through),
+//             every storing wave drains with s_waitcnt vmcnt(0), workgroup barrier, ONE lane stores the flag
+//             (sc1) = epoch;
+//   consumer  ONE wave polls the k flags of its cluster with sc1 loads (relaxed, s_sleep between polls), then a
+//             workgroup barrier, then EVERY load of the payload is an sc1 load to registers (no acquire fence
+//             needed in that form; per-CU L1 is bypassed, placement on XCDs is irrelevant for correctness).
+// Epochs are step + 1, flags are zeroed by a memset node ahead of every launch, payload slots are double-buffered by
+// step parity.  Every spin is bounded (s_memrealtime, ~3 s): on timeout the waiter raises the launch's error word,
+// which every other spin also watches, and all workgroups leave the kernel (outputs are then garbage and the host
+// reports NTK_ERR_HIP from ntk_dnc_cluster_status).  All k * B workgroups must be co-resident: the host caps the
+// grid at one workgroup per CU.
+#pragma once
+#include "dnc_common.h"
+
+constexpr int CT = 512;       // threads per cluster workgroup
+constexpr int CW = CT / 64;   // waves
+
+#define NTK_RLX __ATOMIC_RELAXED
+#define NTK_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ void cl_store(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), NTK_RLX, NTK_AGENT);
+}
+__device__ __forceinline__ void cl_store2(float* p, float a, float b) {           // p 8-byte aligned
+    const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), x, NTK_RLX, NTK_AGENT);
+}
+__device__ __forceinline__ float cl_load(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), NTK_RLX, NTK_AGENT));
+}
+__device__ __forceinline__ void cl_load2(const float* p, float& a, float& b) {    // p 8-byte aligned
+    const unsigned long long x = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), NTK_RLX, NTK_AGENT);
+    a = __uint_as_float((unsigned)x);
+    b = __uint_as_float((unsigned)(x >> 32));
+}
+
+// publish: call from ALL threads of the workgroup after the payload stores
+__device__ __forceinline__ void cl_publish(unsigned* my_flag, unsigned epoch, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(my_flag, epoch, NTK_RLX, NTK_AGENT);
+}
+
+// wait until all k flags of the cluster have reached `epoch`; returns false (uniformly over the workgroup) when the
+// launch was aborted.  s_abort: one int in LDS, zero-initialised before the first call.
+__device__ __forceinline__ bool cl_wait(const unsigned* flags, unsigned epoch, int k, unsigned* err, int* s_abort,
+                                        unsigned long long t_start, int tid) {
+    if (tid < 64) {
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned v = (tid < k) ? __hip_atomic_load(flags + tid, NTK_RLX, NTK_AGENT) : epoch;
+            if (__all((int)(v - epoch) >= 0)) break;
+            if ((++spins & 127u) == 0) {
+                const bool dead = __hip_atomic_load(err, NTK_RLX, NTK_AGENT) != 0 ||
+                                  (__builtin_amdgcn_s_memrealtime() - t_start) > 300000000ull;      // 3 s at 100 MHz
+                if (dead) {
+                    if (tid == 0) { __hip_atomic_store(err, 1u, NTK_RLX, NTK_AGENT); *s_abort = 1; }
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // compiler-only: payload loads stay below the poll
+    __syncthreads();
+    return *s_abort == 0;
+}
+
+// sum over groups of G consecutive lanes (G a power of two <= 64), result in every lane of the group.
+// G <= 16 stays on the DPP data path; 32 / 64 add ds_swizzle / readlane steps.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (G >= 2) v += ntk_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += ntk_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += ntk_dpp<0x141>(v);      // row_half_mirror
+    if constexpr (G >= 16) v += ntk_dpp<0x140>(v);     // row_mirror
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float group_sum_rt(float v, int G) {
+    switch (G) {
+        case 1: return v;
+        case 2: return group_sum<2>(v);
+        case 4: return group_sum<4>(v);
+        case 8: return group_sum<8>(v);
+        case 16: return group_sum<16>(v);
+        case 32: return group_sum<32>(v);
+        default: return group_sum<64>(v);
+    }
+}
+
+// LDS image of the link slice: row r (local), column c -> float index.  float4 groups are XOR-swizzled with the row
+// so that the row-major float4 / scalar accesses of the update and of the backward-read MFMA operand are
+// conflict-free and the column-major scalar reads of the forward-read operand are 4-way at worst.
+__device__ __forceinline__ int cl_lidx(int r, int c, int N) { return r * N + ((((c >> 2) ^ (r & 7))) << 2) + (c & 3); }
+
+struct DncClusterGeom {
+    int k;        // workgroups per sequence
+    int NR;       // link / record rows owned by one workgroup = N / k
+    int upk;      // hidden units per workgroup = ceil(hid / k)
+    int slot0;    // floats per mailbox slot of exchange 0 (controller: h slice + interface partial)
+    int slot1;    // floats per mailbox slot of exchange 1 (link: forward rows + backward partial)
+    int xcd_local;// 1: the k workgroups of a sequence share blockIdx % 8 (same XCD under round-robin placement)
+};
+
+static inline __host__ __device__ int dnc_cluster_align4(int x) { return (x + 3) & ~3; }
+
+// mailbox layout (floats): per sequence [exchange][parity][g][slot]; flags (unsigned): per sequence [exchange][g]
+static inline size_t dnc_cluster_mbox_floats(int B, int k, int slot0, int slot1) {
+    return (size_t)B * 2 * k * ((size_t)slot0 + slot1);
+}

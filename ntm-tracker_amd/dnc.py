@@ -216,8 +216,37 @@ class DNC(object):
         per_step = 4 * B * self._record_floats_per_step()
         return max(1, min(S, self.record_budget_bytes // per_step))
 
+    #: cluster size of the multi-CU sequence kernels: None = automatic (largest that fits), 0 = never (one workgroup
+    #: per sequence, the ntk_dnc_seq_* kernels), k = exactly k or fall back.  NTK_DNC_CLUSTER_K overrides the default.
+    cluster_k = None
+    _cluster = None
+
+    def _cluster_plan(self, B):
+        """(k, workspace tensor) for the cluster kernels at batch B, or None when the shape is outside their range."""
+        import os
+        want = self.cluster_k
+        if want is None and os.environ.get("NTK_DNC_CLUSTER_K"):
+            want = int(os.environ["NTK_DNC_CLUSTER_K"])
+        if want == 0:
+            return None
+        key = (B, want)
+        if self._cluster is None or self._cluster[0] != key:
+            k, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+            rc = _lib.lib().ntk_dnc_cluster_plan(B, self.N, self.W, self.R, self.Wn, self.hid, self.O, int(want or 0),
+                                                 ctypes.byref(k), ctypes.byref(nbytes))
+            ws = torch.empty((nbytes.value + 3) // 4, device=self.device, dtype=torch.float32) if rc == 0 and k.value > 1 else None
+            self._cluster = (key, k.value if ws is not None else 0, ws)
+        return (self._cluster[1], self._cluster[2]) if self._cluster[1] > 1 else None
+
+    def check_cluster(self):
+        """Synchronise and raise if a hand-off of the last cluster launch timed out (tests, end of a benchmark)."""
+        if self._cluster is not None and self._cluster[1] > 1:
+            _lib.check(_lib.lib().ntk_dnc_cluster_status(_P(self._cluster[2]), self._cluster[0][0], self._cluster[1], _lib.stream()),
+                       "ntk_dnc_cluster_status")
+
     def _launch_fwd(self, xproj, B, S, st, rec):
-        """One ntk_dnc_seq_fwd launch over contiguous xproj [B*S, 4*hid] starting from state `st` (not modified)."""
+        """One sequence-kernel launch over contiguous xproj [B*S, 4*hid] starting from state `st` (not modified):
+        the cluster kernel (k CUs per sequence) when the shape allows, else one workgroup per sequence."""
         acc = st.access_state
         # the kernel updates the state in place: work on private copies
         mem, link = acc.memory.clone().contiguous(), acc.linkage.link.clone().contiguous()
@@ -226,10 +255,18 @@ class DNC(object):
         hc = torch.cat([st.controller_state.hidden, st.controller_state.cell], dim=1).contiguous()
         out = torch.empty((B, S, self.O), device=self.device)
         recp = [(_P(rec[k]) if rec else None) for k in self.REC_NAMES]
-        _lib.check(_lib.lib().ntk_dnc_seq_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value,
-                                              _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
-                                              _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), *recp, _lib.stream()),
-                   "ntk_dnc_seq_fwd")
+        plan = self._cluster_plan(B)
+        self.last_cluster_k = plan[0] if plan else 1
+        if plan:
+            _lib.check(_lib.lib().ntk_dnc_cluster_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value, plan[0],
+                                                      _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
+                                                      _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), *recp, _P(plan[1]),
+                                                      _lib.stream()), "ntk_dnc_cluster_fwd")
+        else:
+            _lib.check(_lib.lib().ntk_dnc_seq_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value,
+                                                  _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
+                                                  _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), *recp, _lib.stream()),
+                       "ntk_dnc_seq_fwd")
         new = DNCState(reads, AccessState(mem, rw, ww, TemporalLinkageState(link, prec), usage),
                        LSTMState(hc[:, :self.hid].contiguous(), hc[:, self.hid:].contiguous()))
         return out, new

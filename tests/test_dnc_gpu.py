@@ -274,7 +274,12 @@ def test_dnc_offset_tracker_training_step(cuda):
 def test_dnc_full_length_bptt_gradients_match_autograd_oracle(cuda):
     """BASELINE config 3's cell (DNC 256x64, 4 read heads, hidden 200, clip 20) over S = 650 strictly sequential
     steps (10 serialised frames) of the tracking task, B = 1: loss and every gradient tensor against the float64
-    torch-autograd restatement (direct_offset_output_with_dnc.py:534-541, :615-620).  Per-tensor error printed."""
+    torch-autograd restatement (direct_offset_output_with_dnc.py:534-541, :615-620).
+
+    With Sonnet's default initialisation the key / strength gradients are 1e-5 .. 1e-6 of the largest gradient and are
+    sums with heavy cancellation: a float32 evaluation of the SAME restatement is itself 0.1 - 0.4 off float64 on
+    those tensors.  The bound per tensor is therefore: within 1e-3 of float64, or no further from float64 than
+    3x what the float32 evaluation of the oracle is.  Both columns are printed."""
     from oracle import ntm_oracle as O
     from oracle import ntm_oracle_torch as OT
     from oracle import dnc_oracle_torch as DT
@@ -289,27 +294,116 @@ def test_dnc_full_length_bptt_gradients_match_autograd_oracle(cuda):
     gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
     x = O.serialize_inputs(feats, gts)                                  # [B,S,514]
     offs = rng.uniform(-.5, .5, size=(B, T, 2)).astype(np.float32)
-    t64 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
-    pt = {k: t64(v).requires_grad_(True) for k, v in p.items()}
-    ys, _ = DT.run_model(cfg, pt, t64(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))))
-    loss_ref, _ = OT.offset_loss(ys.permute(1, 0, 2), t64(offs))
-    loss_ref.backward()
+    x_tm = np.ascontiguousarray(np.transpose(x, (1, 0, 2)))
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        tt = lambda v: torch.tensor(np.asarray(v), dtype=dt)
+        pt = {k: tt(v).requires_grad_(True) for k, v in p.items()}
+        ys, _ = DT.run_model(cfg, pt, tt(x_tm))
+        loss_o, _ = OT.offset_loss(ys.permute(1, 0, 2), tt(offs))
+        loss_o.backward()
+        ref[dt] = (float(loss_o.detach()), ys.detach().double().numpy(), {k: v.grad.double().numpy() for k, v in pt.items()})
+    loss_ref, ys_ref, g64 = ref[torch.float64]
+    g32 = ref[torch.float32][2]
 
     core = G.DNC({"memory_size": 256, "word_size": 64, "num_reads": 4, "num_writes": 1}, {"hidden_size": 200}, 2, 20, device=cuda)
     core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
-    out, _st = core.run_sequence(torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).to(cuda), None, record=True)
+    out, _st = core.run_sequence(torch.from_numpy(x_tm).to(cuda), None, record=True)
     assert out.shape == (S, B, 2)
     logits = out.transpose(0, 1).contiguous()
-    np.testing.assert_allclose(logits.cpu().numpy(), ys.permute(1, 0, 2).detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(logits.cpu().numpy(), np.transpose(ys_ref, (1, 0, 2)), atol=1e-4)
     loss, _pred, dlogits = tracker.offset_loss(logits, torch.from_numpy(offs).to(cuda), T)
     grads = core.backward_sequence(core.last_X, dlogits)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(float(loss.cpu()), float(loss_ref.detach()), rtol=1e-4)
-    worst = {}
+    np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-4)
+    rel = lambda a_, b_: float(np.max(np.abs(a_ - b_)) / (np.max(np.abs(b_)) + 1e-30))
+    print("full-length (S=650) DNC gradients vs float64 autograd: tensor, max|ref|, HIP error, float32-oracle error")
+    bad = {}
     for k in sorted(p):
-        ref = pt[k].grad.numpy()
-        worst[k] = float(np.max(np.abs(grads[k].cpu().numpy() - ref)) / (np.max(np.abs(ref)) + 1e-30))
-    print("full-length (S=650) DNC gradient error vs float64 autograd, max|d|/max|ref| per tensor:")
-    for k, v in worst.items():
-        print("  %-36s %.3e" % (k, v))
-    assert max(worst.values()) < 3e-3, worst
+        e_hip, e_f32 = rel(grads[k].cpu().numpy(), g64[k]), rel(g32[k], g64[k])
+        print("  %-36s %.3e  %.3e  %.3e" % (k, np.abs(g64[k]).max(), e_hip, e_f32))
+        if e_hip > max(1e-3, 3 * e_f32):
+            bad[k] = (e_hip, e_f32)
+    assert not bad, bad
+
+
+CLUSTER_CASES = [
+    # name, N, W, R, hid, S, B, cluster sizes to try
+    ("c3_shape", 256, 64, 4, 200, 6, 2, (2, 4, 8)),
+    ("small_64x16", 64, 16, 2, 24, 7, 3, (2, 4, 8)),
+    ("r1_128x32", 128, 32, 1, 40, 5, 1, (4,)),
+    ("r3_odd_hidden", 128, 20, 3, 36, 5, 2, (8,)),
+]
+
+
+@pytest.mark.parametrize("name,N,W,R,hid,S,B,ks", CLUSTER_CASES, ids=[c[0] for c in CLUSTER_CASES])
+def test_dnc_cluster_forward_equals_single_workgroup_kernel(cuda, name, N, W, R, hid, S, B, ks):
+    """The cluster form (k workgroups per sequence, LDS-resident link rows, two mailbox exchanges per step) against the
+    one-workgroup-per-sequence kernel (itself checked against the oracle above): outputs, final state and EVERY BPTT
+    record, from a random non-degenerate state, for several cluster sizes."""
+    from ntmtrack import dnc as G
+    Din, O = 12, 2
+    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=1, hidden_size=hid, clip_value=20.0)
+    rng = np.random.default_rng(31)
+    p = D.init_params(cfg, rng)
+    for kk in p:
+        if kk.endswith("/b") or kk.endswith("b_gates"):
+            p[kk] = rng.uniform(-0.3, 0.3, size=p[kk].shape).astype(np.float32)
+        if kk.startswith("memory_access/") and kk.endswith("/w"):
+            p[kk] = (p[kk] * 6).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((S, B, Din)).astype(np.float32)).to(cuda)
+    st0 = _random_state(cfg, B, rng)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(cuda)
+    a0 = st0.access_state
+    gst = G.DNCState(t(st0.access_output), G.AccessState(t(a0.memory), t(a0.read_weights), t(a0.write_weights),
+                     G.TemporalLinkageState(t(a0.linkage.link), t(a0.linkage.precedence_weights)), t(a0.usage)),
+                     G.LSTMState(t(st0.controller_state.hidden), t(st0.controller_state.cell)))
+
+    def run(k):
+        core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, 20.0, device=cuda)
+        core.load_state_dict({kk: torch.from_numpy(v) for kk, v in p.items()})
+        core.cluster_k = k
+        out, st = core.run_sequence(x, gst, record=True)
+        core.check_cluster()
+        assert core.last_cluster_k == max(k, 1), (core.last_cluster_k, k)
+        torch.cuda.synchronize()
+        return out, st, core.last_record
+
+    ref_out, ref_st, ref_rec = run(0)
+    for k in ks:
+        out, st, rec = run(k)
+        tol = dict(atol=2e-5, rtol=0)
+        np.testing.assert_allclose(out.cpu().numpy(), ref_out.cpu().numpy(), err_msg="out k=%d" % k, **tol)
+        for nm, a_, b_ in (("memory", st.access_state.memory, ref_st.access_state.memory),
+                           ("link", st.access_state.linkage.link, ref_st.access_state.linkage.link),
+                           ("usage", st.access_state.usage, ref_st.access_state.usage),
+                           ("rw", st.access_state.read_weights, ref_st.access_state.read_weights),
+                           ("ww", st.access_state.write_weights, ref_st.access_state.write_weights),
+                           ("prec", st.access_state.linkage.precedence_weights, ref_st.access_state.linkage.precedence_weights),
+                           ("reads", st.access_output, ref_st.access_output),
+                           ("h", st.controller_state.hidden, ref_st.controller_state.hidden),
+                           ("c", st.controller_state.cell, ref_st.controller_state.cell)):
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), err_msg="%s k=%d" % (nm, k), **tol)
+        for nm in G.DNC.REC_NAMES:
+            np.testing.assert_allclose(rec[nm].cpu().numpy(), ref_rec[nm].cpu().numpy(), err_msg="record %s k=%d" % (nm, k), **tol)
+
+
+def test_dnc_cluster_forward_full_length_is_deterministic(cuda):
+    """Config 3 at full size (B 32, S 1300, k = 8: all 256 CUs): two launches are bitwise identical, no hand-off times
+    out, and sequence 5 inside the batch equals sequence 5 alone (run as its own cluster launch)."""
+    from ntmtrack import dnc as G
+    B, S = 32, 1300
+    core = G.DNC({"memory_size": 256, "word_size": 64, "num_reads": 4, "num_writes": 1}, {"hidden_size": 200}, 2, 20.0,
+                 input_dim=514, device=cuda, seed=4)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((S, B, 514), generator=g).to(cuda) * 0.5
+    o1, s1 = core.run_sequence(x)
+    core.check_cluster()
+    assert core.last_cluster_k == 8
+    o2, s2 = core.run_sequence(x)
+    core.check_cluster()
+    assert torch.equal(o1, o2) and torch.equal(s1.access_state.linkage.link, s2.access_state.linkage.link)
+    assert torch.isfinite(o1).all()
+    o5, _ = core.run_sequence(x[:, 5:6].contiguous())
+    core.check_cluster()
+    assert torch.equal(o5[:, 0], o1[:, 5])

@@ -191,8 +191,9 @@ def test_load_state_dict_keeps_the_optimiser_bound(cuda):
 
 def test_full_length_bptt_gradients_match_autograd_oracle(cuda):
     """BASELINE config 2's full horizon: T = 20 frames -> S = 1300 strictly sequential steps of BPTT, B = 2, gradients
-    of every tensor against the float64 torch-autograd restatement (direct_offset_output.py:611-621).  The bound is
-    what fp32 storage + fp32 accumulation over 1300 dependent steps gives against float64, printed per tensor."""
+    of every tensor against the float64 torch-autograd restatement (direct_offset_output.py:611-621).  The bound (5e-5 per
+    tensor, relative to the tensor's largest entry) is ~10x what fp32 storage + fp32 accumulation over 1300 dependent
+    steps measures against float64; the per-tensor errors are printed."""
     from ntmtrack.ntm import NTMCell
     from ntmtrack import tracker
     name, kw, D, _T, _B, scale = GRAD_CASES[0]
@@ -227,4 +228,4 @@ def test_full_length_bptt_gradients_match_autograd_oracle(cuda):
     print("full-length (S=1300) NTM gradient error vs float64 autograd, max|d|/max|ref| per tensor:")
     for k, v in worst.items():
         print("  %-24s %.3e" % (k, v))
-    assert max(worst.values()) < 1e-3, worst
+    assert max(worst.values()) < 5e-5, worst          # measured 2e-8 .. 4e-6 (GPUTEST r2)
