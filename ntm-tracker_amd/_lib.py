@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntmtrack_hip.so")
+# NTK_LIB_PATH: developer override (e.g. the diagnostic build `make -C csrc prof`); the product loads the in-tree library
+LIB_PATH = os.environ.get("NTK_LIB_PATH") or os.path.join(_HERE, "libntmtrack_hip.so")
 
 _lib = None
 

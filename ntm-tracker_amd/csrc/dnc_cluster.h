@@ -102,16 +102,74 @@ __device__ __forceinline__ float group_sum_rt(float v, int G) {
 // conflict-free and the column-major scalar reads of the forward-read operand are 4-way at worst.
 __device__ __forceinline__ int cl_lidx(int r, int c, int N) { return r * N + ((((c >> 2) ^ (r & 7))) << 2) + (c & 3); }
 
-struct DncClusterGeom {
-    int k;        // workgroups per sequence
-    int NR;       // link / record rows owned by one workgroup = N / k
-    int upk;      // hidden units per workgroup = ceil(hid / k)
-    int slot0;    // floats per mailbox slot of exchange 0 (controller: h slice + interface partial)
-    int slot1;    // floats per mailbox slot of exchange 1 (link: forward rows + backward partial)
-    int xcd_local;// 1: the k workgroups of a sequence share blockIdx % 8 (same XCD under round-robin placement)
+// Everything about a launch that depends only on the SHAPE (memory N x W, R read heads, hidden size, outputs, cluster
+// size k): interface offsets, padded leading dimensions, the work decomposition of a step and the magic reciprocals
+// that replace integer divisions in the kernels.  One constexpr function fills it, on the host for every launch and at
+// COMPILE time for the benchmark shape (the FIX instantiations of the kernels fold all of it into immediates, which
+// is what keeps their uniform state inside the 102 SGPRs a wave has).
+struct DncClusterCfg {
+    int N, W, R, hid, O;
+    int I, IP, K, ldz, ldh, Ky, ldy, OP;
+    int oV, oE, oF, oAg, oWg, oRm, oKw, oBw, oKr, oBr;
+    int k;            // workgroups per sequence
+    int NR;           // link / record rows owned by one workgroup = N / k
+    int upk, upkp;    // hidden units per workgroup = ceil(hid / k), rounded up to 4
+    int slot0;        // floats per mailbox slot of exchange 0 (controller: h slice + interface partial)
+    int slot1;        // floats per mailbox slot of exchange 1 (link: forward rows + backward partial)
+    int ksl, kperG;   // gate product: K-slices, rows per slice (a thread = one own unit x one slice)
+    int icg, nslI, uperI;   // interface partial: float4 column groups, unit slices, units per slice
+    int nslA, mperA;  // rank computation: slices of the slot range, slots per slice
+    int strips, NRp;  // N / 64, NR rounded up to 32
+    int HW4;          // float4s of a memory row per thread of the row pair
+    int nperW;        // memory rows per wave in the read-vector product
+    // magic reciprocals: x / dv == __umulhi(x, mg) for x * dv < 2^32 (mg = ceil(2^32 / dv), dv >= 2; 0 means dv == 1)
+    unsigned mg_upk, mg_icg, mg_NR, mg_N, mg_N4, mg_W4;
 };
 
-static inline __host__ __device__ int dnc_cluster_align4(int x) { return (x + 3) & ~3; }
+constexpr int CLT = 512;      // threads per cluster workgroup (= CT below)
+
+static constexpr __host__ __device__ int dnc_cluster_align4(int x) { return (x + 3) & ~3; }
+static constexpr __host__ __device__ int dnc_cluster_max(int a, int b) { return a > b ? a : b; }
+static constexpr __host__ __device__ unsigned dnc_cluster_magic(int dv) {
+    return dv <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)dv - 1) / (unsigned)dv);
+}
+__device__ __forceinline__ int cl_div(int x, unsigned mg) { return mg ? (int)__umulhi((unsigned)x, mg) : x; }
+
+static constexpr __host__ __device__ DncClusterCfg dnc_cluster_cfg(int N, int W, int R, int hid, int O, int k) {
+    DncClusterCfg c = {};
+    c.N = N; c.W = W; c.R = R; c.hid = hid; c.O = O; c.k = k;
+    // interface layout and padded widths (num_writes = 1): as dnc_fill_dims (dnc_common.h)
+    c.oV = 0; c.oE = W; c.oF = 2 * W; c.oAg = c.oF + R; c.oWg = c.oAg + 1; c.oRm = c.oWg + 1; c.oKw = c.oRm + 3 * R;
+    c.oBw = c.oKw + W; c.oKr = c.oBw + 1; c.oBr = c.oKr + R * W; c.I = c.oBr + R; c.IP = (c.I + 3) & ~3;
+    c.K = R * W + hid; c.ldz = (c.K + 1 + 3) & ~3; c.ldh = (hid + 1 + 3) & ~3;
+    c.Ky = hid + R * W; c.ldy = (c.Ky + 1 + 3) & ~3; c.OP = (O + 3) & ~3;
+    c.NR = N / k;
+    c.upk = (hid + k - 1) / k;
+    c.upkp = dnc_cluster_align4(c.upk);
+    c.slot0 = dnc_cluster_align4(c.upkp + c.IP);
+    c.slot1 = dnc_cluster_align4(R * c.NR + R * N);
+    c.ksl = dnc_cluster_max(1, CLT / dnc_cluster_max(1, c.upk));
+    if (c.ksl > c.K) c.ksl = c.K;
+    c.kperG = (c.K + c.ksl - 1) / c.ksl;
+    c.icg = c.IP / 4;
+    c.nslI = dnc_cluster_max(1, CLT / c.icg);
+    c.uperI = (c.upk + c.nslI - 1) / c.nslI;
+    c.nslA = dnc_cluster_max(1, CLT / N);
+    c.mperA = N / c.nslA;
+    c.strips = N / 64;
+    c.NRp = ((c.NR + 31) / 32) * 32;
+    c.HW4 = (W / 4 + 1) / 2;
+    c.nperW = N / (CLT / 64);
+    c.mg_upk = dnc_cluster_magic(c.upk); c.mg_icg = dnc_cluster_magic(c.icg); c.mg_NR = dnc_cluster_magic(c.NR);
+    c.mg_N = dnc_cluster_magic(N); c.mg_N4 = dnc_cluster_magic(N / 4); c.mg_W4 = dnc_cluster_magic(W / 4);
+    return c;
+}
+
+// the benchmark shape (BASELINE configs[2]: DNC 256 x 64, 4 read heads, hidden 200, 2 outputs) at 8 workgroups per sequence
+constexpr DncClusterCfg kDncClusterFixCfg = dnc_cluster_cfg(256, 64, 4, 200, 2, 8);
+static inline bool dnc_cluster_is_fix(const DncClusterCfg& c) {
+    return c.N == 256 && c.W == 64 && c.R == 4 && c.hid == 200 && c.O == 2 && c.k == 8;
+}
 
 // mailbox layout (floats): per sequence [exchange][parity][g][slot]; flags (unsigned): per sequence [exchange][g]
 static inline size_t dnc_cluster_mbox_floats(int B, int k, int slot0, int slot1) {

@@ -21,11 +21,66 @@
 // (exact fp32 FMA chains, k-ordered: same numerics as a scalar loop).
 #include "dnc_cluster.h"
 
+// Diagnostic build only (-DNTK_CL_PROF): workgroup 0 accumulates s_memtime deltas per phase (its wave 0, lane 0) into
+// g_cl_prof; ntk_dnc_cluster_prof() copies them out.  The stamps serialise the phases: read SHARES, not totals.
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_cl_prof[32];
+#define CL_STAMP(i)                                                                   \
+    do {                                                                              \
+        if (blockIdx.x == 0 && tid == 0) {                                            \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+            prof_acc[i] += now_ - prof_last;                                          \
+            prof_last = now_;                                                         \
+        }                                                                             \
+    } while (0)
+#else
+#define CL_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
+struct DncClFwdLds {
+    int part, M, L, Z, C, I, K, U, NU, KEY, RANK, RW, RWT, WW, P, CW, CR, SC, total;
+};
+
+// LDS carve-up (offsets in floats) of a shape: constexpr, so the FIX kernel sees immediates
+constexpr __host__ __device__ DncClFwdLds dnc_cl_fwd_lds(const DncClusterCfg& c) {
+    DncClFwdLds L = {};
+    const int N = c.N, RWd = c.R * c.W;
+    int part = c.ksl * c.upk * 4;
+    part = dnc_cluster_max(part, c.nslI * c.IP);
+    part = dnc_cluster_max(part, c.nslA * N + N);          // rank partials + the rank-ordered usage vector
+    part = dnc_cluster_max(part, c.strips * 2 * c.NRp * 4);
+    part = dnc_cluster_max(part, CW * RWd);
+    int o = 0;
+    L.part = o; o += dnc_cluster_align4(part);
+    L.M = o; o += dnc_cluster_align4(N * (c.W + 4));       // rows padded by one float4: a thread pair walks ONE row conflict-free
+    L.L = o; o += dnc_cluster_align4(c.NR * N);
+    L.Z = o; o += dnc_cluster_align4(c.K);
+    L.C = o; o += dnc_cluster_align4(c.upk);
+    L.I = o; o += dnc_cluster_align4(c.IP);
+    L.K = o; o += dnc_cluster_align4((1 + c.R) * c.W);
+    L.U = o; o += dnc_cluster_align4(N);
+    L.NU = o; o += dnc_cluster_align4(N);
+    L.KEY = o; o += dnc_cluster_align4(2 * N);
+    L.RANK = o; o += dnc_cluster_align4(N);
+    L.RW = o; o += dnc_cluster_align4(c.R * N);
+    L.RWT = o; o += dnc_cluster_align4(4 * N);
+    L.WW = o; o += dnc_cluster_align4(N);
+    L.P = o; o += dnc_cluster_align4(N);
+    L.CW = o; o += dnc_cluster_align4(N);
+    L.CR = o; o += dnc_cluster_align4(c.R * N);
+    L.SC = o; o += 64;
+    L.total = o;
+    return L;
+}
+constexpr DncClFwdLds kDncClFixFwdLds = dnc_cl_fwd_lds(kDncClusterFixCfg);
+
 struct DncClFwdArgs {
-    DncDims d;
-    DncClusterGeom g;
+    int B, S, xcd_local;
+    float clip;
+    DncClusterCfg c;
+    DncClFwdLds lds;
     const float* xproj; const float* Wr; const float* Wi; const float* Wy;
     float* mem; float* link; float* usage; float* rw; float* ww; float* prec; float* reads; float* hc; float* out;
     float* rec_z; float* rec_gates; float* rec_c; float* rec_hc; float* rec_yin; float* rec_ifc; float* rec_u;
@@ -33,35 +88,6 @@ struct DncClFwdArgs {
     float* rec_bwd; float* rec_M; float* rec_L; float* rec_ypre;
     float* mbox; unsigned* flags; unsigned* err;
 };
-
-struct DncClFwdLds {
-    int part, M, L, Z, C, I, U, NU, RW, WW, P, CW, CR, SC, total;
-};
-
-int cl_imax(int a, int b) { return a > b ? a : b; }
-
-void dnc_cl_fwd_lds(const DncDims& d, const DncClusterGeom& g, DncClFwdLds& L) {
-    const int N = d.N, RWd = d.R * d.W, W4 = d.W / 4;
-    const int ksl = cl_imax(1, CT / cl_imax(1, g.upk));
-    const int icg = d.IP / 4, nslI = cl_imax(1, CT / icg);
-    const int nslA = cl_imax(1, CT / N);
-    const int strips = N / 64, NRp = ((g.NR + 31) / 32) * 32;
-    const int nslR = cl_imax(1, CT / (d.R * W4));
-    int part = ksl * g.upk * 4;
-    part = cl_imax(part, nslI * d.IP);
-    part = cl_imax(part, nslA * N);
-    part = cl_imax(part, strips * 2 * NRp * 4);
-    part = cl_imax(part, nslR * RWd);
-    int o = 0;
-    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    L.part = take(part);
-    L.M = take(N * d.W);
-    L.L = take(g.NR * N);
-    L.Z = take(d.K); L.C = take(g.upk); L.I = take(d.IP);
-    L.U = take(N); L.NU = take(N); L.RW = take(d.R * N); L.WW = take(N); L.P = take(N); L.CW = take(N); L.CR = take(d.R * N);
-    L.SC = take(64);
-    L.total = o;
-}
 
 __device__ __forceinline__ void cl_softmax_row(float* r, int N, int lane) {      // one wave, in place
     float mx = -INFINITY;
@@ -73,114 +99,131 @@ __device__ __forceinline__ void cl_softmax_row(float* r, int N, int lane) {     
     for (int n = lane; n < N; n += 64) r[n] = r[n] / s;
 }
 
-__global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, DncClFwdLds L) {
+__device__ __forceinline__ float cl_dot4(const f32x4& x, const f32x4& y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3]; }
+__device__ __forceinline__ float cl_pair_sum(float v) { return v + ntk_dpp<0xB1>(v); }      // lanes 2p, 2p+1
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// LDS views and launch constants derived from the shape configuration C and the LDS layout L in scope
+#define CL_FWD_VIEWS()                                                                                                        \
+    const int k = C.k, NR = C.NR, upk = C.upk, upkp = C.upkp;                                                                 \
+    const int N = C.N, W = C.W, R = C.R;                                                                                      \
+    const int hid = C.hid, K = C.K, IP = C.IP, RWd = R * W, N4 = N >> 2, W4 = W >> 2, WS = W + 4, WS4 = W4 + 1;               \
+    const int row0 = g * NR, u0 = min(hid, g * upk), u1 = min(hid, u0 + upk), nU = u1 - u0;                                   \
+    float* sPart = smem + L.part; float* sM = smem + L.M; float* sL = smem + L.L;                                             \
+    float* sZ = smem + L.Z; float* sC = smem + L.C; float* sI = smem + L.I; float* sK = smem + L.K;                            \
+    float* sU = smem + L.U; float* sNU = smem + L.NU;                                                                         \
+    unsigned long long* sKEY = reinterpret_cast<unsigned long long*>(smem + L.KEY);                                          \
+    int* sRank = reinterpret_cast<int*>(smem + L.RANK);                                                                       \
+    float* sRW = smem + L.RW; float* sRWT = smem + L.RWT; float* sWW = smem + L.WW;                                           \
+    float* sP = smem + L.P; float* sCW = smem + L.CW; float* sCR = smem + L.CR;                                               \
+    float* sSC = smem + L.SC; int* sAbort = reinterpret_cast<int*>(sSC + 32);                                                 \
+    f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart); f32x4* sM4 = reinterpret_cast<f32x4*>(sM);                              \
+    f32x4* sL4 = reinterpret_cast<f32x4*>(sL); const f32x4* sK4 = reinterpret_cast<const f32x4*>(sK);                        \
+    (void)upkp; (void)K; (void)IP; (void)RWd; (void)N4; (void)WS; (void)WS4; (void)u1; (void)nU; (void)sPart4; (void)sK4;    \
+    (void)sKEY; (void)sRank; (void)sNU; (void)sCW; (void)sCR; (void)sK; (void)sAbort; (void)sL; (void)sM; (void)sRWT; (void)sI; (void)sC; (void)k
+
+// FIX: the benchmark shape (kDncClusterFixCfg) with every dimension, offset and LDS address a compile-time constant:
+// the short per-row and per-slot loops unroll, their LDS loads are issued in batches instead of one dependent load
+// per iteration (the first version of this kernel spent 60 % of a step waiting for such loads), and the uniform
+// state fits the SGPR file.  The generic instantiation reads the same values from the kernarg segment INSIDE the
+// time loop (through a pointer made opaque once per step), so they are not hoisted and spilled.
+template <bool FIX>
+__global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DncDims& d = a.d;
+    typedef const __attribute__((address_space(4))) DncClFwdArgs* ArgsK;
+    const ArgsK ak0 = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     const int tid0 = threadIdx.x;
-    const int k = a.g.k, NR = a.g.NR, upk = a.g.upk;
+    const int kk0 = FIX ? kDncClusterFixCfg.k : a0.c.k;
     int b, g;
-    if (a.g.xcd_local) {                    // the k members of a sequence share blockIdx % 8 (speed only, never correctness)
+    if (a0.xcd_local) {                     // the k members of a sequence share blockIdx % 8 (speed only, never correctness)
         const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
-        b = x + 8 * (s / k);
-        g = s % k;
+        b = x + 8 * (s / kk0);
+        g = s % kk0;
     } else {
-        b = blockIdx.x / k;
-        g = blockIdx.x % k;
+        b = blockIdx.x / kk0;
+        g = blockIdx.x % kk0;
     }
-    const int N = d.N, W = d.W, R = d.R, hid = d.hid, S = d.S, K = d.K, IP = d.IP, RWd = R * W, N4 = N >> 2, W4 = W >> 2;
-    const float clipv = d.clip;
     const float EPS = 1e-6f;
-    const int row0 = g * NR;                                  // first link row / memory row / slot owned by this workgroup
-    const int u0 = min(hid, g * upk), u1 = min(hid, u0 + upk), nU = u1 - u0;
-    const int upkp = dnc_cluster_align4(upk);
-
-    float* sPart = smem + L.part;
-    float* sM = smem + L.M;
-    float* sL = smem + L.L;
-    float* sZ = smem + L.Z;      // [reads_prev ; h_prev]
-    float* sC = smem + L.C;      // cell of the own units
-    float* sI = smem + L.I;
-    float* sU = smem + L.U;
-    float* sNU = smem + L.NU;    // nonusage 1 - (eps + (1 - eps) u): the allocation order is decided on these stored values
-    float* sRW = smem + L.RW;
-    float* sWW = smem + L.WW;
-    float* sP = smem + L.P;
-    float* sCW = smem + L.CW;
-    float* sCR = smem + L.CR;
-    float* sSC = smem + L.SC;
-    int* sAbort = reinterpret_cast<int*>(sSC + 32);
-    f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
-    f32x4* sM4 = reinterpret_cast<f32x4*>(sM);
-    f32x4* sL4 = reinterpret_cast<f32x4*>(sL);
-
-    // mailbox of this sequence
-    const int slot0 = a.g.slot0, slot1 = a.g.slot1;
-    float* mb0 = a.mbox + (size_t)b * 2 * k * ((size_t)slot0 + slot1);        // [parity][g][slot0]
-    float* mb1 = mb0 + (size_t)2 * k * slot0;                                 // [parity][g][slot1]
-    unsigned* fl0 = a.flags + (size_t)b * 2 * k;
-    unsigned* fl1 = fl0 + k;
+    const int S = a0.S;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 
-    int LPR = 1;
-    while (LPR * 4 < W) LPR <<= 1;
-    const int ngrp = CT / LPR;
-
     // ---- load state (memory replicated, link rows of this workgroup, per-slot vectors replicated)
-    if (tid0 == 0) *sAbort = 0;
     {
+        const DncClFwdArgs& a = a0;
+        const DncClusterCfg C = FIX ? kDncClusterFixCfg : a.c;
+        const DncClFwdLds L = FIX ? kDncClFixFwdLds : a.lds;
+        CL_FWD_VIEWS();
+        if (tid0 == 0) *sAbort = 0;
         const f32x4* gM4 = reinterpret_cast<const f32x4*>(a.mem + (size_t)b * N * W);
-        for (int i = tid0; i < N * W4; i += CT) sM4[i] = gM4[i];
+        for (int i = tid0; i < N * W4; i += CT) { const int n = i / W4, j = i - n * W4; sM4[n * WS4 + j] = gM4[i]; }
         const f32x4* gL4 = reinterpret_cast<const f32x4*>(a.link + ((size_t)b * N + row0) * N);
         for (int i = tid0; i < NR * N4; i += CT) {
             const int r = i / N4, q = i - r * N4;
             sL4[r * N4 + (q ^ (r & 7))] = gL4[i];
         }
+        for (int i = tid0; i < N; i += CT) {
+            sU[i] = a.usage[(size_t)b * N + i];
+            sWW[i] = a.ww[(size_t)b * N + i];
+            sP[i] = a.prec[(size_t)b * N + i];
+        }
+        for (int i = tid0; i < 4 * N; i += CT) sRWT[i] = 0.f;
+        for (int i = tid0; i < R * N; i += CT) sRW[i] = a.rw[(size_t)b * R * N + i];
+        for (int i = tid0; i < RWd; i += CT) sZ[i] = a.reads[(size_t)b * RWd + i];
+        for (int i = tid0; i < hid; i += CT) sZ[RWd + i] = a.hc[(size_t)b * 2 * hid + i];
+        for (int i = tid0; i < nU; i += CT) sC[i] = a.hc[(size_t)b * 2 * hid + hid + u0 + i];
+        for (int i = tid0; i < (1 + R) * W; i += CT) sK[i] = 0.f;
     }
-    for (int i = tid0; i < N; i += CT) {
-        sU[i] = a.usage[(size_t)b * N + i];
-        sWW[i] = a.ww[(size_t)b * N + i];
-        sP[i] = a.prec[(size_t)b * N + i];
-    }
-    for (int i = tid0; i < R * N; i += CT) sRW[i] = a.rw[(size_t)b * R * N + i];
-    for (int i = tid0; i < RWd; i += CT) sZ[i] = a.reads[(size_t)b * RWd + i];
-    for (int i = tid0; i < hid; i += CT) sZ[RWd + i] = a.hc[(size_t)b * 2 * hid + i];
-    for (int i = tid0; i < nU; i += CT) sC[i] = a.hc[(size_t)b * 2 * hid + hid + u0 + i];
     __syncthreads();
 
-    const f32x4* Wr4 = reinterpret_cast<const f32x4*>(a.Wr);
-    const f32x4* Wi4 = reinterpret_cast<const f32x4*>(a.Wi);
-    const bool rec = a.rec_z != nullptr;
-
-    // work decomposition (constant over the sequence)
-    const int ksl = max(1, min(K, CT / max(1, nU))), kperG = (K + ksl - 1) / ksl;
-    const int icg = IP >> 2, nslI = max(1, CT / icg), uperI = (max(nU, 1) + nslI - 1) / nslI;
-    const int nslA = max(1, CT / N), mperA = (N + nslA - 1) / nslA;
-    const int strips = N >> 6, NRp = ((NR + 31) >> 5) << 5;
-    const int nRW4 = R * W4, nslR = max(1, CT / nRW4), nperR = (N + nslR - 1) / nslR;
-
+#ifdef NTK_CL_PROF
+    unsigned long long prof_acc[16] = {0}, prof_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < S; ++t) {
+        ArgsK ak = ak0;
+        asm volatile("" : "+s"(ak));
+        const auto& a = *ak;
+        DncClusterCfg C = kDncClusterFixCfg;
+        DncClFwdLds L = kDncClFixFwdLds;
+        if constexpr (!FIX) {                  // generic shape: (dead fields of) the two blocks come from the kernarg segment
+            __builtin_memcpy(&C, (const void*)&a.c, sizeof(C));
+            __builtin_memcpy(&L, (const void*)&a.lds, sizeof(L));
+        }
+        CL_FWD_VIEWS();
+        const float clipv = a.clip;
+        const int ksl = C.ksl, kperG = C.kperG, icg = C.icg, nslI = C.nslI, uperI = C.uperI;
+        const int nslA = C.nslA, mperA = C.mperA, strips = C.strips, NRp = C.NRp, HW4 = C.HW4, nperW = C.nperW;
+        const int slot0 = C.slot0, slot1 = C.slot1;
+        float* mb0 = a.mbox + (size_t)b * 2 * k * ((size_t)slot0 + slot1);        // [parity][g][slot0]
+        float* mb1 = mb0 + (size_t)2 * k * slot0;                                 // [parity][g][slot1]
+        unsigned* fl0 = a.flags + (size_t)b * 2 * k;
+        unsigned* fl1 = fl0 + k;
+        const f32x4* Wr4 = reinterpret_cast<const f32x4*>(a.Wr);
+        const f32x4* Wi4 = reinterpret_cast<const f32x4*>(a.Wi);
+        const bool rec = a.rec_z != nullptr;
         int tid_op = tid0;
         asm volatile("" : "+v"(tid_op));       // keep per-thread index math inside the step (no hoist + spill)
         const int tid = tid_op, lane = tid & 63, wave = tid >> 6;
         const size_t bt = (size_t)b * S + t;
         const unsigned epoch = (unsigned)t + 1u;
         const int par = t & 1;
+        CL_STAMP(15);
 
         // ------------------------------------------------------------ P1: LSTM gates of the own hidden units
         f32x4 xg = {0.f, 0.f, 0.f, 0.f};
         if (tid < nU) xg = reinterpret_cast<const f32x4*>(a.xproj)[bt * hid + u0 + tid] + Wr4[(size_t)K * hid + u0 + tid];
-        if (rec && g == 0) for (int i = tid; i < d.ldz; i += CT) a.rec_z[bt * d.ldz + i] = (i < K) ? sZ[i] : (i == K ? 1.f : 0.f);
-        if (tid < ksl * nU) {
-            const int j = tid % nU, ks = tid / nU;
+        if (rec && g == 0) for (int i = tid; i < C.ldz; i += CT) a.rec_z[bt * C.ldz + i] = (i < K) ? sZ[i] : (i == K ? 1.f : 0.f);
+        if (tid < ksl * upk) {
+            const int ks = cl_div(tid, C.mg_upk), j = tid - ks * upk;
             const int k0 = ks * kperG, k1 = min(K, k0 + kperG);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (k0 < k1) acc = ntk_stream_matvec<4>(Wr4 + u0 + j, hid, sZ, k0, k1, K - 1);
-            sPart4[ks * nU + j] = acc;
+            if (j < nU && k0 < k1) acc = ntk_stream_matvec<4>(Wr4 + u0 + j, hid, sZ, k0, k1, K - 1);
+            sPart4[ks * upk + j] = acc;
         }
         __syncthreads();
         if (tid < nU) {
             f32x4 gsum = xg;
-            for (int ks = 0; ks < ksl; ++ks) gsum += sPart4[ks * nU + tid];
+            for (int ks = 0; ks < ksl; ++ks) gsum += sPart4[ks * upk + tid];
             const float gi = dnc_sigmoid(gsum[0]), gj = tanhf(gsum[1]);
             const float gf = dnc_sigmoid(gsum[2] + 1.0f);            // snt.LSTM forget_bias = 1.0
             const float go = dnc_sigmoid(gsum[3]);
@@ -195,17 +238,19 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
             }
         }
         __syncthreads();
+        CL_STAMP(0);
         // ------------------------------------------------------------ P2: interface partial sums over the own units
         if (tid < nslI * icg) {
-            const int cg = tid % icg, us = tid / icg;
+            const int us = cl_div(tid, C.mg_icg), cg = tid - us * icg;
             const int ua = u0 + us * uperI, ub = min(u1, ua + uperI);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const f32x4* wp = Wi4 + (size_t)ua * icg + cg;
-#pragma unroll 4
+#pragma unroll 8
             for (int u = ua; u < ub; ++u, wp += icg) acc += sZ[RWd + u] * (*wp);
             sPart4[us * icg + cg] = acc;
         }
         __syncthreads();
+        CL_STAMP(1);
         {   // publish exchange 0: [h of the own units | interface partial]
             float* slot = mb0 + ((size_t)par * k + g) * slot0;
             if (tid < nU) cl_store(slot + tid, sZ[RWd + u0 + tid]);
@@ -216,11 +261,13 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
             }
             cl_publish(fl0 + g, epoch, tid);
         }
+        CL_STAMP(2);
         if (!cl_wait(fl0, epoch, k, a.err, sAbort, t_start, tid)) return;
-        {   // consume exchange 0: full h, activated interface
+        CL_STAMP(3);
+        {   // consume exchange 0: full h, activated interface (+ aligned copies of the keys)
             const float* base = mb0 + (size_t)par * k * slot0;
             for (int u = tid; u < hid; u += CT) {
-                const int gg = u / upk;
+                const int gg = cl_div(u, C.mg_upk);
                 sZ[RWd + u] = cl_load(base + (size_t)gg * slot0 + (u - gg * upk));
             }
             for (int c = tid; c < IP; c += CT) {
@@ -231,162 +278,225 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) if (gg < k) v += pv[gg];
                 float r = v;
-                if (c >= d.oE && c < d.oRm) r = dnc_sigmoid(v);                      // erase, free, alloc, write gates
-                else if ((c >= d.oBw && c < d.oKr) || (c >= d.oBr && c < d.I)) r = dnc_softplus(v);   // strengths
+                if (c >= C.oE && c < C.oRm) r = dnc_sigmoid(v);                      // erase, free, alloc, write gates
+                else if ((c >= C.oBw && c < C.oKr) || (c >= C.oBr && c < C.I)) r = dnc_softplus(v);   // strengths
                 sI[c] = r;
+                if (c >= C.oKw && c < C.oBw) sK[c - C.oKw] = r;
+                else if (c >= C.oKr && c < C.oBr) sK[W + (c - C.oKr)] = r;
             }
         }
         __syncthreads();
+        CL_STAMP(4);
         if (rec && g == 0) {
-            for (int i = tid; i < d.ldh; i += CT) {
+            for (int i = tid; i < C.ldh; i += CT) {
                 const float v = (i < hid) ? sZ[RWd + i] : (i == hid ? 1.f : 0.f);
-                a.rec_hc[bt * d.ldh + i] = v;
-                if (i < hid) a.rec_yin[bt * d.ldy + i] = v;
+                a.rec_hc[bt * C.ldh + i] = v;
+                if (i < hid) a.rec_yin[bt * C.ldy + i] = v;
+            }
+            for (int c = tid; c < IP; c += CT) {
+                float v = sI[c];
+                if (c >= C.oRm && c < C.oKw) {             // the read modes are recorded after their softmax (computed below)
+                    const float* rm = sI + C.oRm + ((c - C.oRm) / 3) * 3;
+                    const float mx = fmaxf(rm[0], fmaxf(rm[1], rm[2]));
+                    const float e0 = expf(rm[0] - mx), e1 = expf(rm[1] - mx), e2 = expf(rm[2] - mx);
+                    v = expf(v - mx) / (e0 + e1 + e2);
+                }
+                a.rec_ifc[bt * IP + c] = v;
             }
         }
-        if (tid < R) {                                                               // read_mode softmax (access.py:186-187)
-            float* rm = sI + d.oRm + tid * 3;
-            const float mx = fmaxf(rm[0], fmaxf(rm[1], rm[2]));
-            const float e0 = expf(rm[0] - mx), e1 = expf(rm[1] - mx), e2 = expf(rm[2] - mx);
-            const float s = e0 + e1 + e2;
-            rm[0] = e0 / s; rm[1] = e1 / s; rm[2] = e2 / s;
+        // key norms: wave i < 1 + R  ->  sSC[8 + i] = sqrt(|key_i|^2 + eps)
+        if (wave < 1 + R) {
+            float ss = 0.f;
+            for (int w = lane; w < W; w += 64) { const float kv = sK[wave * W + w]; ss += kv * kv; }
+            ss = wave_sum(ss);
+            if (lane == 0) sSC[8 + wave] = sqrtf(ss + EPS);
         }
         // ------------------------------------------------------------ P3: usage (addressing.py:342-374), op by op
         {
 #pragma clang fp contract(off)
+            float fg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fg[i] = (i < R) ? sI[C.oF + i] : 0.f;
             for (int n = tid; n < N; n += CT) {
                 float pw = 1.f;
                 pw *= (1.0f - sWW[n]);
                 float u = sU[n];
                 u = u + (1.0f - u) * (1.0f - pw);
                 float phi = 1.f;
-                for (int i = 0; i < R; ++i) phi *= (1.0f - sI[d.oF + i] * sRW[i * N + n]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i < R) phi *= (1.0f - fg[i] * sRW[i * N + n]);
                 u *= phi;
                 sU[n] = u;
-                sNU[n] = 1.0f - (EPS + (1.0f - EPS) * u);
-            }
-        }
-        // ------------------------------------------------------------ P4: write content weights on M_{t-1}
-        {
-            const int grp = tid / LPR, gl = tid % LPR;
-            f32x4 kw = {0.f, 0.f, 0.f, 0.f};
-            if (gl < W4) { const float* kp = sI + d.oKw + gl * 4; kw = f32x4{kp[0], kp[1], kp[2], kp[3]}; }
-            const float ksq = group_sum_rt(kw[0] * kw[0] + kw[1] * kw[1] + kw[2] * kw[2] + kw[3] * kw[3], LPR);
-            const float kn = sqrtf(ksq + EPS), bw = sI[d.oBw];
-            for (int n = grp; n < N; n += ngrp) {
-                f32x4 m = {0.f, 0.f, 0.f, 0.f};
-                if (gl < W4) m = sM4[n * W4 + gl];
-                float nsq = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3];
-                float dot = kw[0] * m[0] + kw[1] * m[1] + kw[2] * m[2] + kw[3] * m[3];
-                nsq = group_sum_rt(nsq, LPR);
-                dot = group_sum_rt(dot, LPR);
-                if (gl == 0) sCW[n] = (dot / (kn * sqrtf(nsq + EPS) + EPS)) * bw;
+                const float nu = 1.0f - (EPS + (1.0f - EPS) * u);
+                sNU[n] = nu;
+                // sort key of the allocation: larger nonusage first, ties to the lower slot (tf.nn.top_k); nonusage >= +0,
+                // so its bit pattern orders like its value
+                sKEY[n] = ((unsigned long long)__float_as_uint(nu) << 32) | (unsigned)(0xFFFF - n);
+                if (rec && n >= row0 && n < row0 + NR) a.rec_u[bt * N + n] = u;
             }
         }
         __syncthreads();
-        if (wave == 0) cl_softmax_row(sCW, N, lane);
-        if (rec) {                                           // the own slots of the per-slot records (sU final since the barrier)
-            for (int n = tid; n < NR; n += CT) a.rec_u[bt * N + row0 + n] = sU[row0 + n];
-            if (g == 0) for (int c = tid; c < IP; c += CT) a.rec_ifc[bt * IP + c] = sI[c];
+        if (tid < R) {                                                               // read_mode softmax (access.py:186-187)
+            float* rm = sI + C.oRm + tid * 3;
+            const float mx = fmaxf(rm[0], fmaxf(rm[1], rm[2]));
+            const float e0 = expf(rm[0] - mx), e1 = expf(rm[1] - mx), e2 = expf(rm[2] - mx);
+            const float s = e0 + e1 + e2;
+            rm[0] = e0 / s; rm[1] = e1 / s; rm[2] = e2 / s;
         }
-        // ------------------------------------------------------------ P5: allocation (rank form) + write weights
+        CL_STAMP(5);
+        // ------------------------------------------------------------ P4: write content scores on M_{t-1}: a thread PAIR per row
+        {
+            const int h = tid & 1, j0 = h * HW4, j1 = min(W4, j0 + HW4);
+            const float kn = sSC[8], bw = sI[C.oBw];
+            for (int n = tid >> 1; n < N; n += CT / 2) {
+                float nsq = 0.f, dot = 0.f;
+                const f32x4* mr = sM4 + n * WS4;
+#pragma unroll 4
+                for (int j = j0; j < j1; ++j) { const f32x4 m = mr[j]; nsq += cl_dot4(m, m); dot += cl_dot4(sK4[j], m); }
+                nsq = cl_pair_sum(nsq);
+                dot = cl_pair_sum(dot);
+                if (h == 0) sCW[n] = (dot / (kn * sqrtf(nsq + EPS) + EPS)) * bw;
+            }
+        }
+        // ------------------------------------------------------------ P5a: rank of every slot in the usage order
         if (tid < nslA * N) {
-            const int n = tid % N, sl = tid / N;
-            const float nun = sNU[n];
-            const int m0 = sl * mperA, m1 = min(N, m0 + mperA);
-            float prod = 1.f;
-            for (int m = m0; m < m1; ++m) {
-                const float num = sNU[m];
-                const bool before = (num > nun) || (num == nun && m < n);
-                prod *= before ? (1.0f - num) : 1.0f;
+            const int sl = (FIX ? tid / N : cl_div(tid, C.mg_N)), n = tid - sl * N;
+            const unsigned long long mine = sKEY[n];
+            const u64x2* kp = reinterpret_cast<const u64x2*>(sKEY + sl * mperA);
+            int cnt = 0;
+            for (int m = 0; m < mperA; m += 8) {
+                const u64x2 k0 = kp[(m >> 1)], k1 = kp[(m >> 1) + 1], k2 = kp[(m >> 1) + 2], k3 = kp[(m >> 1) + 3];
+                cnt += (k0[0] > mine) + (k0[1] > mine) + (k1[0] > mine) + (k1[1] > mine) + (k2[0] > mine) + (k2[1] > mine) +
+                       (k3[0] > mine) + (k3[1] > mine);
             }
-            sPart[sl * N + n] = prod;
+            reinterpret_cast<int*>(sPart)[sl * N + n] = cnt;
         }
         __syncthreads();
+        CL_STAMP(6);
+        // ------------------------------------------------------------ P5b: usages scattered into rank order; write-content softmax
         {
-#pragma clang fp contract(off)
-            const float ag = sI[d.oAg], wg = sI[d.oWg];
+            float* sT = sPart + nslA * N;
             for (int n = tid; n < N; n += CT) {
-                float prod = 1.f;
-                for (int sl = 0; sl < nslA; ++sl) prod *= sPart[sl * N + n];
-                const float al = sNU[n] * prod;
-                const float cw = sCW[n];
-                sWW[n] = wg * (ag * al + (1.0f - ag) * cw);
-                if (rec && n >= row0 && n < row0 + NR) { a.rec_al[bt * N + n] = al; a.rec_cw[bt * N + n] = cw; }
+                int rk = 0;
+                for (int sl = 0; sl < nslA; ++sl) rk += reinterpret_cast<const int*>(sPart)[sl * N + n];
+                sRank[n] = rk;
+                sT[rk] = 1.0f - sNU[n];                    // sorted_usage = 1 - sorted_nonusage (addressing.py:398)
+            }
+            if (wave == CW - 1) cl_softmax_row(sCW, N, lane);
+            __syncthreads();
+            // P5c: exclusive cumulative product in rank order (tf.cumprod(exclusive=True), addressing.py:399) by wave 0
+            if (wave == 0) {
+                const int PER = N >> 6, base = lane * PER;
+                float ex[8], run = 1.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < PER) { ex[j] = run; run *= sT[base + j]; }
+                float inc = run;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const float o = __shfl_up(inc, dd, 64); if (lane >= dd) inc *= o; }
+                float excl = __shfl_up(inc, 1, 64);
+                if (lane == 0) excl = 1.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < PER) sT[base + j] = excl * ex[j];
+            }
+            __syncthreads();
+            // P5d: allocation and write weights (access.py:220-257), op by op
+            {
+#pragma clang fp contract(off)
+                const float ag = sI[C.oAg], wg = sI[C.oWg];
+                for (int n = tid; n < N; n += CT) {
+                    const float al = sNU[n] * sT[sRank[n]];
+                    const float cw = sCW[n];
+                    sWW[n] = wg * (ag * al + (1.0f - ag) * cw);
+                    if (rec && n >= row0 && n < row0 + NR) { a.rec_al[bt * N + n] = al; a.rec_cw[bt * N + n] = cw; }
+                }
             }
         }
         __syncthreads();
+        CL_STAMP(7);
         // ------------------------------------------------------------ P6: erase + write on M (every row), read-key scores on M_t
         {
-            const int grp = tid / LPR, gl = tid % LPR;
-            f32x4 ev = {0.f, 0.f, 0.f, 0.f}, vv = ev, kr[4];
-            float krn[4];
+            const int h = tid & 1, j0 = h * HW4, j1 = min(W4, j0 + HW4);
+            const f32x4* sE4 = reinterpret_cast<const f32x4*>(sI + C.oE);
+            const f32x4* sV4 = reinterpret_cast<const f32x4*>(sI + C.oV);
+            float krn[4], br[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kr[i] = ev;
-            if (gl < W4) {
-                ev = *reinterpret_cast<const f32x4*>(sI + d.oE + gl * 4);
-                vv = *reinterpret_cast<const f32x4*>(sI + d.oV + gl * 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < R) { const float* kp = sI + d.oKr + i * W + gl * 4; kr[i] = f32x4{kp[0], kp[1], kp[2], kp[3]}; }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                krn[i] = sqrtf(group_sum_rt(kr[i][0] * kr[i][0] + kr[i][1] * kr[i][1] + kr[i][2] * kr[i][2] + kr[i][3] * kr[i][3], LPR) + EPS);
-            for (int n = grp; n < N; n += ngrp) {
-                f32x4 m = {0.f, 0.f, 0.f, 0.f};
-                if (gl < W4) {
-                    m = sM4[n * W4 + gl];
-                    const float wwn = sWW[n];
+            for (int i = 0; i < 4; ++i) { krn[i] = (i < R) ? sSC[9 + i] : 1.f; br[i] = (i < R) ? sI[C.oBr + i] : 0.f; }
+            for (int n = tid >> 1; n < N; n += CT / 2) {
+                const float wwn = sWW[n];
+                const bool own = rec && n >= row0 && n < row0 + NR;
+                f32x4* mr = sM4 + n * WS4;
+                float nsq = 0.f, dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+                for (int j = j0; j < j1; ++j) {
+                    f32x4 m = mr[j];
+                    const f32x4 ev = sE4[j], vv = sV4[j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) m[e] = m[e] * (1.0f - wwn * ev[e]) + wwn * vv[e];
-                    sM4[n * W4 + gl] = m;
-                    if (rec && n >= row0 && n < row0 + NR) reinterpret_cast<f32x4*>(a.rec_M + (bt * N + n) * W)[gl] = m;
+                    mr[j] = m;
+                    if (own) reinterpret_cast<f32x4*>(a.rec_M + (bt * N + n) * W)[j] = m;
+                    nsq += cl_dot4(m, m);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (i < R) dot[i] += cl_dot4(sK4[(1 + i) * W4 + j], m);
                 }
-                float nsq = group_sum_rt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3], LPR);
+                nsq = cl_pair_sum(nsq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i < R) dot[i] = cl_pair_sum(dot[i]);
                 const float nm = sqrtf(nsq + EPS);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < R) {
-                        float dot = kr[i][0] * m[0] + kr[i][1] * m[1] + kr[i][2] * m[2] + kr[i][3] * m[3];
-                        dot = group_sum_rt(dot, LPR);
-                        if (gl == 0) sCR[i * N + n] = (dot / (krn[i] * nm + EPS)) * sI[d.oBr + i];
+                for (int i = 0; i < 4; ++i)
+                    if (i < R && (i & 1) == h) sCR[i * N + n] = (dot[i] / (krn[i] * nm + EPS)) * br[i];
+            }
+        }
+        CL_STAMP(8);
+        // ------------------------------------------------------------ P7a: link update of the own rows (LDS in place)
+        for (int base = tid; base < NR * N4; base += 4 * CT) {
+            f32x4 l[4];
+            int ph[4], rr[4], qq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gi = base + u * CT;
+                rr[u] = (FIX ? gi / N4 : cl_div(gi, C.mg_N4)); qq[u] = gi - rr[u] * N4;
+                ph[u] = rr[u] * N4 + (qq[u] ^ (rr[u] & 7));
+                if (gi < NR * N4) l[u] = sL4[ph[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (base + u * CT < NR * N4) {
+                    const int r = rr[u], q = qq[u];
+                    const float wwa = sWW[row0 + r];
+                    const f32x4 wwb = *reinterpret_cast<const f32x4*>(sWW + 4 * q);
+                    const f32x4 pb = *reinterpret_cast<const f32x4*>(sP + 4 * q);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (1.0f - wwa - wwb[e]) * l[u][e] + wwa * pb[e];
+                        if (4 * q + e == row0 + r) v[e] = 0.f;                    // matrix_set_diag(link, 0)
                     }
+                    sL4[ph[u]] = v;
+                    if (rec) reinterpret_cast<f32x4*>(a.rec_L + (bt * N + row0 + r) * N)[q] = v;
                 }
             }
         }
-        // ------------------------------------------------------------ P7a: link update of the own rows (LDS in place)
-        for (int gi = tid; gi < NR * N4; gi += CT) {
-            const int r = gi / N4, q = gi - r * N4;
-            const int ph = r * N4 + (q ^ (r & 7));
-            f32x4 l = sL4[ph];
-            const float wwa = sWW[row0 + r];
-            const f32x4 wwb = *reinterpret_cast<const f32x4*>(sWW + 4 * q);
-            const f32x4 pb = *reinterpret_cast<const f32x4*>(sP + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = (1.0f - wwa - wwb[e]) * l[e] + wwa * pb[e];
-                if (4 * q + e == row0 + r) v = 0.f;                               // matrix_set_diag(link, 0)
-                l[e] = v;
-            }
-            sL4[ph] = l;
-            if (rec) reinterpret_cast<f32x4*>(a.rec_L + (bt * N + row0 + r) * N)[q] = l;
-        }
         __syncthreads();
+        CL_STAMP(9);
         // ------------------------------------------------------------ P7b: directional reads on the 4x4x1 MFMA
         float* slot1p = mb1 + ((size_t)par * k + g) * slot1;                       // [fwd R x NR | bwd partial R x N]
         for (int job = wave; job < 2 * strips; job += CW) {
             const int hsel = lane & 3;
+            const bool hok = hsel < R;
             if (job < strips) {                              // backward: column sums over the own rows
                 const int c = 64 * job + lane;
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                 const float* rwp = sRW + hsel * N + row0;
-                const bool hok = hsel < R;
-                for (int r = 0; r < NR; r += 2) {
-                    const float a0 = hok ? rwp[r] : 0.f, a1 = hok ? rwp[r + 1] : 0.f;
-                    const float b0 = sL[cl_lidx(r, c, N)], b1 = sL[cl_lidx(r + 1, c, N)];
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, acc1, 0, 0, 0);
+                for (int r = 0; r < NR; r += 8) {            // NR a multiple of 8
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { av[q] = rwp[r + q]; bv[q] = sL[cl_lidx(r + q, c, N)]; }
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(hok ? av[q] : 0.f, bv[q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(hok ? av[q + 1] : 0.f, bv[q + 1], acc1, 0, 0, 0);
+                    }
                 }
                 acc0 += acc1;
 #pragma unroll
@@ -394,18 +504,21 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
             } else {                                         // forward: row sums of the own rows over a 64-column range
                 const int rg = job - strips;
                 const int par2 = lane >> 5;
-                const bool hok = hsel < R;
                 const float* rwp = sRW + hsel * N + 64 * rg + par2;
                 for (int rb = 0; rb < NRp; rb += 32) {
                     const int row = rb + (lane & 31);
                     const bool rok = row < NR;
+                    const int rowc = rok ? row : 0;
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-                    for (int s = 0; s < 32; s += 2) {
-                        const int c0 = 64 * rg + 2 * s + par2, c1 = c0 + 2;
-                        const float a0 = rok ? sL[cl_lidx(row, c0, N)] : 0.f, a1 = rok ? sL[cl_lidx(row, c1, N)] : 0.f;
-                        const float b0 = hok ? rwp[2 * s] : 0.f, b1 = hok ? rwp[2 * s + 2] : 0.f;
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, b0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, acc1, 0, 0, 0);
+                    for (int s = 0; s < 32; s += 8) {
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { av[q] = sL[cl_lidx(rowc, 64 * rg + 2 * (s + q) + par2, N)]; bv[q] = rwp[2 * (s + q)]; }
+#pragma unroll
+                        for (int q = 0; q < 8; q += 2) {
+                            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(rok ? av[q] : 0.f, hok ? bv[q] : 0.f, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(rok ? av[q + 1] : 0.f, hok ? bv[q + 1] : 0.f, acc1, 0, 0, 0);
+                        }
                     }
                     acc0 += acc1;
                     // D[v] of this lane = (row rb + 4 * ((lane >> 2) & 7) + v, head lane & 3), column parity lane >> 5
@@ -416,8 +529,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
             }
         }
         __syncthreads();
+        CL_STAMP(10);
         for (int idx = tid; idx < R * NR; idx += CT) {       // forward reads of the own rows: fixed-order sum of the partials
-            const int i = idx / NR, r = idx - i * NR;
+            const int i = cl_div(idx, C.mg_NR), r = idx - i * NR;
             float f = 0.f;
             for (int q = 0; q < 2 * strips; ++q) f += sPart[(q * NRp + r) * 4 + i];
             cl_store(slot1p + idx, f);
@@ -430,13 +544,15 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
             if (lane == 0) sSC[0] = s;
         }
         cl_publish(fl1 + g, epoch, tid);
+        CL_STAMP(11);
         if (!cl_wait(fl1, epoch, k, a.err, sAbort, t_start, tid)) return;
+        CL_STAMP(12);
         // ------------------------------------------------------------ P8: read weights, precedence, reads, output
         {
             const float* base = mb1 + (size_t)par * k * slot1;
             for (int idx = tid; idx < R * N; idx += CT) {
-                const int i = idx / N, n = idx - i * N;
-                const int og = n / NR;
+                const int i = (FIX ? idx / N : cl_div(idx, C.mg_N)), n = idx - i * N;
+                const int og = cl_div(n, C.mg_NR);
                 float pv[8];
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? cl_load(base + (size_t)gg * slot1 + R * NR + idx) : 0.f;
@@ -444,10 +560,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
                 float bwd = 0.f;
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) if (gg < k) bwd += pv[gg];
-                const float* rm = sI + d.oRm + i * 3;
+                const float* rm = sI + C.oRm + i * 3;
                 const float cr = sCR[idx];
                 const float v = rm[2] * cr + rm[1] * fwd + rm[0] * bwd;                // access.py:283-303 (num_writes = 1)
                 sRW[idx] = v;
+                sRWT[n * 4 + i] = v;
                 if (rec && n >= row0 && n < row0 + NR) {
                     a.rec_rw[bt * R * N + idx] = v;
                     a.rec_cr[bt * R * N + idx] = cr;
@@ -455,70 +572,99 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
                     a.rec_bwd[bt * R * N + idx] = bwd;
                 }
             }
+            const float sww = sSC[0];
             for (int n = tid; n < N; n += CT) {
-                const float pn = (1.0f - sSC[0]) * sP[n] + sWW[n];                      // addressing.py:238-240
+                const float pn = (1.0f - sww) * sP[n] + sWW[n];                         // addressing.py:238-240
                 sP[n] = pn;
                 if (rec && n >= row0 && n < row0 + NR) { a.rec_p[bt * N + n] = pn; a.rec_ww[bt * N + n] = sWW[n]; }
             }
         }
         __syncthreads();
-        if (tid < nslR * nRW4) {                              // reads = rw x M_t
-            const int o = tid % nRW4, sl = tid / nRW4;
-            const int i = o / W4, w4 = o - i * W4;
-            const int n0 = sl * nperR, n1 = min(N, n0 + nperR);
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int n = n0; n < n1; ++n) s += sRW[i * N + n] * sM4[n * W4 + w4];
-            sPart4[sl * nRW4 + o] = s;
+        CL_STAMP(13);
+        // reads = rw x M_t on the 4x4x1 MFMA (the "backward" form: block = 4 columns of the word, one memory row per
+        // instruction); wave w sums its N / 8 rows, the eight partial vectors are added in a fixed order
+        for (int cs = 0; cs < W; cs += 64) {
+            const int c = cs + lane;
+            const bool cok = c < W;
+            const int cc = cok ? c : 0;
+            const int hsel = lane & 3;
+            const float* mp = sM + cc;
+            const float* rwt = sRWT + hsel;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            const int nA = wave * nperW;
+            for (int n = nA; n < nA + nperW; n += 8) {       // N a multiple of 64: nperW a multiple of 8
+                float av[8], bv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { av[q] = rwt[(n + q) * 4]; bv[q] = mp[(n + q) * WS]; }
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q], cok ? bv[q] : 0.f, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q + 1], cok ? bv[q + 1] : 0.f, acc1, 0, 0, 0);
+                }
+            }
+            acc0 += acc1;
+            if (cok) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) if (v < R) sPart[(wave * R + v) * W + c] = acc0[v];
+            }
         }
         __syncthreads();
         if (tid < RWd) {
             float s = 0.f;
-            for (int sl = 0; sl < nslR; ++sl) s += sPart[sl * RWd + tid];
+#pragma unroll
+            for (int w = 0; w < CW; ++w) s += sPart[w * RWd + tid];
             sZ[tid] = s;
-            if (rec && g == 0) a.rec_yin[bt * d.ldy + hid + tid] = s;
-        } else if (rec && g == 0 && tid < RWd + (d.ldy - d.Ky)) {
-            a.rec_yin[bt * d.ldy + d.Ky + (tid - RWd)] = (tid == RWd) ? 1.f : 0.f;
+            if (rec && g == 0) a.rec_yin[bt * C.ldy + hid + tid] = s;
+        } else if (rec && g == 0 && tid < RWd + (C.ldy - C.Ky)) {
+            a.rec_yin[bt * C.ldy + C.Ky + (tid - RWd)] = (tid == RWd) ? 1.f : 0.f;
         }
         __syncthreads();
         if (g == 0) {
-            for (int o = wave; o < d.O; o += CW) {            // y = clip([h ; reads] Wy + by)   (dnc.py:118-122)
+            for (int o = wave; o < C.O; o += CW) {            // y = clip([h ; reads] Wy + by)   (dnc.py:118-122)
                 float s = 0.f;
-                for (int kk = lane; kk < d.Ky; kk += 64) {
+                for (int kk = lane; kk < C.Ky; kk += 64) {
                     const float zv = (kk < hid) ? sZ[RWd + kk] : sZ[kk - hid];
-                    s += zv * a.Wy[(size_t)kk * d.OP + o];
+                    s += zv * a.Wy[(size_t)kk * C.OP + o];
                 }
                 s = wave_sum(s);
                 if (lane == 0) {
-                    const float pre = s + a.Wy[(size_t)d.Ky * d.OP + o];
-                    a.out[bt * d.O + o] = dnc_clip(pre, clipv);
-                    if (rec) a.rec_ypre[bt * d.O + o] = pre;
+                    const float pre = s + a.Wy[(size_t)C.Ky * C.OP + o];
+                    a.out[bt * C.O + o] = dnc_clip(pre, clipv);
+                    if (rec) a.rec_ypre[bt * C.O + o] = pre;
                 }
             }
         }
+        CL_STAMP(14);
     }
+#ifdef NTK_CL_PROF
+    if (blockIdx.x == 0 && tid0 == 0) for (int i = 0; i < 16; ++i) g_cl_prof[i] = prof_acc[i];
+#endif
     __syncthreads();
 
     // ---- store state: own rows of memory and link, own units of the cell; the replicated vectors by workgroup 0
     {
+        const DncClFwdArgs& a = a0;
+        const DncClusterCfg C = FIX ? kDncClusterFixCfg : a.c;
+        const DncClFwdLds L = FIX ? kDncClFixFwdLds : a.lds;
+        CL_FWD_VIEWS();
         f32x4* gM4 = reinterpret_cast<f32x4*>(a.mem + ((size_t)b * N + row0) * W);
-        for (int i = tid0; i < NR * W4; i += CT) gM4[i] = sM4[row0 * W4 + i];
+        for (int i = tid0; i < NR * W4; i += CT) { const int n = i / W4, j = i - n * W4; gM4[i] = sM4[(row0 + n) * WS4 + j]; }
         f32x4* gL4 = reinterpret_cast<f32x4*>(a.link + ((size_t)b * N + row0) * N);
         for (int i = tid0; i < NR * N4; i += CT) {
             const int r = i / N4, q = i - r * N4;
             gL4[i] = sL4[r * N4 + (q ^ (r & 7))];
         }
-    }
-    for (int i = tid0; i < nU; i += CT) a.hc[(size_t)b * 2 * hid + hid + u0 + i] = sC[i];
-    if (g == 0) {
-        for (int i = tid0; i < N; i += CT) {
-            a.usage[(size_t)b * N + i] = sU[i];
-            a.ww[(size_t)b * N + i] = sWW[i];
-            a.prec[(size_t)b * N + i] = sP[i];
+        for (int i = tid0; i < nU; i += CT) a.hc[(size_t)b * 2 * hid + hid + u0 + i] = sC[i];
+        if (g == 0) {
+            for (int i = tid0; i < N; i += CT) {
+                a.usage[(size_t)b * N + i] = sU[i];
+                a.ww[(size_t)b * N + i] = sWW[i];
+                a.prec[(size_t)b * N + i] = sP[i];
+            }
+            for (int i = tid0; i < R * N; i += CT) a.rw[(size_t)b * R * N + i] = sRW[i];
+            for (int i = tid0; i < RWd; i += CT) a.reads[(size_t)b * RWd + i] = sZ[i];
+            for (int i = tid0; i < hid; i += CT) a.hc[(size_t)b * 2 * hid + i] = sZ[RWd + i];
         }
-        for (int i = tid0; i < R * N; i += CT) a.rw[(size_t)b * R * N + i] = sRW[i];
-        for (int i = tid0; i < RWd; i += CT) a.reads[(size_t)b * RWd + i] = sZ[i];
-        for (int i = tid0; i < hid; i += CT) a.hc[(size_t)b * 2 * hid + i] = sZ[RWd + i];
     }
 }
 
@@ -527,23 +673,25 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a, Dnc
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-static int dnc_cluster_geom(int B, int N, int W, int R, int Wn, int hid, int O, int k_req, DncDims& d, DncClusterGeom& g,
-                            size_t* lds_bytes) {
-    dnc_fill_dims(d, B, 1, N, W, R, Wn, hid, O, 0.f);
-    if (Wn != 1 || R < 1 || R > 4 || N < 64 || (N % 64) != 0 || N > 1024 || W < 4 || (W % 4) != 0 || W > 256 || hid < 4 ||
-        hid > 1024 || O < 1 || O > CW || B < 1 || (d.IP / 4) > CT || R * (W / 4) > CT)
+#ifdef NTK_CL_PROF
+extern "C" int ntk_dnc_cluster_prof(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cl_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#endif
+
+// the cluster size (0 = none) and configuration of a shape; k_req 0 = the largest k that fits
+static int dnc_cluster_pick(int B, int N, int W, int R, int Wn, int hid, int O, int k_req, DncClusterCfg& c, size_t* lds_bytes) {
+    if (Wn != 1 || R < 1 || R > 4 || N < 64 || (N % 64) != 0 || N > CT || W < 4 || (W % 4) != 0 || W > 256 || hid < 4 ||
+        hid > 1024 || O < 1 || O > CW || B < 1)
         return 0;
     for (int k = 8; k >= 1; k >>= 1) {
         if (k_req > 0 && k != k_req) continue;
         if ((long)B * k > 256) continue;                       // one workgroup per CU, all co-resident
         const int NR = N / k;
-        if (NR * k != N || NR < 8 || (NR % 4) != 0) continue;
-        g.k = k; g.NR = NR; g.upk = (hid + k - 1) / k;
-        g.slot0 = dnc_cluster_align4(dnc_cluster_align4(g.upk) + d.IP);
-        g.slot1 = dnc_cluster_align4(R * NR + R * N);
-        g.xcd_local = 0;
-        DncClFwdLds L;
-        dnc_cl_fwd_lds(d, g, L);
+        if (NR * k != N || NR < 8 || (NR % 8) != 0) continue;
+        c = dnc_cluster_cfg(N, W, R, hid, O, k);
+        if (c.icg > CT || R * (W / 4) > CT) continue;
+        const DncClFwdLds L = dnc_cl_fwd_lds(c);
         const size_t bytes = (size_t)L.total * sizeof(float);
         if (bytes > 160 * 1024) continue;
         if (lds_bytes) *lds_bytes = bytes;
@@ -557,18 +705,17 @@ static size_t dnc_cluster_ctrl_bytes(int B, int k) { return (((size_t)B * 2 * k 
 
 extern "C" int ntk_dnc_cluster_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k,
                                     size_t* workspace_bytes) {
-    DncDims d;
-    DncClusterGeom g;
-    const int kk = dnc_cluster_geom(B, N, W, R, Wn, hid, O, k_request, d, g, nullptr);
+    DncClusterCfg c;
+    const int kk = dnc_cluster_pick(B, N, W, R, Wn, hid, O, k_request, c, nullptr);
     if (k) *k = kk;
     if (workspace_bytes) *workspace_bytes = 0;
     if (kk <= 0) {
         ntk_set_error("ntk_dnc_cluster_plan: B=%d N=%d W=%d R=%d Wn=%d hid=%d is outside the cluster kernels' range "
-                      "(num_writes 1, memory_size a multiple of 64, link rows and memory LDS resident, B * k <= 256)",
+                      "(num_writes 1, memory_size a multiple of 64 up to 512, link rows and memory LDS resident, B * k <= 256)",
                       B, N, W, R, Wn, hid);
         return NTK_ERR_UNSUPPORTED;
     }
-    if (workspace_bytes) *workspace_bytes = dnc_cluster_ctrl_bytes(B, kk) + dnc_cluster_mbox_floats(B, kk, g.slot0, g.slot1) * sizeof(float);
+    if (workspace_bytes) *workspace_bytes = dnc_cluster_ctrl_bytes(B, kk) + dnc_cluster_mbox_floats(B, kk, c.slot0, c.slot1) * sizeof(float);
     return NTK_OK;
 }
 
@@ -594,10 +741,11 @@ extern "C" int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, in
     DncClFwdArgs a;
     size_t lds_bytes = 0;
     NTK_REQUIRE(B > 0 && S > 0 && k > 0, NTK_ERR_BAD_SHAPE, "ntk_dnc_cluster_fwd: B=%d S=%d k=%d", B, S, k);
-    const int kk = dnc_cluster_geom(B, N, W, R, Wn, hid, O, k, a.d, a.g, &lds_bytes);
+    const int kk = dnc_cluster_pick(B, N, W, R, Wn, hid, O, k, a.c, &lds_bytes);
     NTK_REQUIRE(kk == k, NTK_ERR_UNSUPPORTED, "ntk_dnc_cluster_fwd: k=%d is not a valid cluster size for B=%d N=%d W=%d R=%d Wn=%d hid=%d "
                 "(ask ntk_dnc_cluster_plan)", k, B, N, W, R, Wn, hid);
-    dnc_fill_dims(a.d, B, S, N, W, R, Wn, hid, O, clip_value);
+    a.lds = dnc_cl_fwd_lds(a.c);
+    a.B = B; a.S = S; a.clip = clip_value;
     NTK_REQUIRE(xproj && Wr && Wi && Wy && mem && link && usage && rw && ww && prec && reads && hc && out && workspace, NTK_ERR_BAD_PTR,
                 "ntk_dnc_cluster_fwd: null pointer");
     NTK_REQUIRE(ntk_aligned16(xproj) && ntk_aligned16(Wr) && ntk_aligned16(Wi) && ntk_aligned16(mem) && ntk_aligned16(link) &&
@@ -611,7 +759,7 @@ extern "C" int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, in
         NTK_REQUIRE(nn == 0 || (ntk_aligned16(rec_gates) && ntk_aligned16(rec_M) && ntk_aligned16(rec_L)), NTK_ERR_BAD_PTR,
                     "ntk_dnc_cluster_fwd: rec_gates/rec_M/rec_L must be 16-byte aligned");
     }
-    a.g.xcd_local = (B % 8) == 0 ? 1 : 0;
+    a.xcd_local = (B % 8) == 0 ? 1 : 0;
     a.xproj = xproj; a.Wr = Wr; a.Wi = Wi; a.Wy = Wy; a.mem = mem; a.link = link; a.usage = usage; a.rw = rw; a.ww = ww;
     a.prec = prec; a.reads = reads; a.hc = hc; a.out = out;
     a.rec_z = rec_z; a.rec_gates = rec_gates; a.rec_c = rec_c; a.rec_hc = rec_hc; a.rec_yin = rec_yin; a.rec_ifc = rec_ifc;
@@ -621,17 +769,16 @@ extern "C" int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, in
     a.flags = reinterpret_cast<unsigned*>(workspace);
     a.err = a.flags + (size_t)B * 2 * k;
     a.mbox = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ctrl);
-    DncClFwdLds L;
-    dnc_cl_fwd_lds(a.d, a.g, L);
     {
         static NtkLdsAttrCache lds_cache;
-        const void* const ks[] = {(const void*)dnc_cluster_fwd_kernel};
-        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 1, "ntk_dnc_cluster_fwd");
+        const void* const ks[] = {(const void*)dnc_cluster_fwd_kernel<false>, (const void*)dnc_cluster_fwd_kernel<true>};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 2, "ntk_dnc_cluster_fwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
     hipError_t e = hipMemsetAsync(workspace, 0, ctrl, (hipStream_t)stream);     // flags + error word: zero before EVERY launch
     NTK_REQUIRE(e == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    dnc_cluster_fwd_kernel<<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a, L);
+    if (dnc_cluster_is_fix(a.c)) dnc_cluster_fwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
+    else dnc_cluster_fwd_kernel<false><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     NTK_CHECK_LAUNCH("ntk_dnc_cluster_fwd");
     return NTK_OK;
 }

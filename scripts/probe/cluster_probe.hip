@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
         if (!ok) for (int l = 0; l < 8; ++l) printf("  lane %d: %g %g %g %g\n", l, D[l * 4], D[l * 4 + 1], D[l * 4 + 2], D[l * 4 + 3]);
     }
     const int k = argc > 1 ? atoi(argv[1]) : 8, clusters = argc > 2 ? atoi(argv[2]) : 32, steps = argc > 3 ? atoi(argv[3]) : 20000;
-    const int words = 1024;
+    const int words = argc > 4 ? atoi(argv[4]) : 1024;
     unsigned *flags, *err, *bad; unsigned long long* mbox;
     hipMalloc(&flags, clusters * k * 4 + 64); hipMalloc(&err, 64); hipMalloc(&bad, 64);
     hipMalloc(&mbox, (size_t)clusters * 2 * k * words * 8);

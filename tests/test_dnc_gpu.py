@@ -365,13 +365,18 @@ def test_dnc_cluster_forward_equals_single_workgroup_kernel(cuda, name, N, W, R,
         core.cluster_k = k
         out, st = core.run_sequence(x, gst, record=True)
         core.check_cluster()
-        assert core.last_cluster_k == max(k, 1), (core.last_cluster_k, k)
         torch.cuda.synchronize()
-        return out, st, core.last_record
+        return out, st, core.last_record, core.last_cluster_k
 
-    ref_out, ref_st, ref_rec = run(0)
+    ref_out, ref_st, ref_rec, used = run(0)
+    assert used == 1
+    tried = 0
     for k in ks:
-        out, st, rec = run(k)
+        out, st, rec, used = run(k)
+        if used != k:                 # this cluster size does not fit (e.g. 128 link rows x 256 do not fit LDS beside the memory)
+            assert used == 1
+            continue
+        tried += 1
         tol = dict(atol=2e-5, rtol=0)
         np.testing.assert_allclose(out.cpu().numpy(), ref_out.cpu().numpy(), err_msg="out k=%d" % k, **tol)
         for nm, a_, b_ in (("memory", st.access_state.memory, ref_st.access_state.memory),
@@ -386,6 +391,7 @@ def test_dnc_cluster_forward_equals_single_workgroup_kernel(cuda, name, N, W, R,
             np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), err_msg="%s k=%d" % (nm, k), **tol)
         for nm in G.DNC.REC_NAMES:
             np.testing.assert_allclose(rec[nm].cpu().numpy(), ref_rec[nm].cpu().numpy(), err_msg="record %s k=%d" % (nm, k), **tol)
+    assert tried >= 1, "no cluster size of %s was usable" % (ks,)
 
 
 def test_dnc_cluster_forward_full_length_is_deterministic(cuda):
