@@ -238,11 +238,30 @@ class DNC(object):
             self._cluster = (key, k.value if ws is not None else 0, ws)
         return (self._cluster[1], self._cluster[2]) if self._cluster[1] > 1 else None
 
+    _cluster_b = None
+
+    def _cluster_bwd_plan(self, B):
+        """(k, workspace) for the cluster BPTT kernel at batch B, or None (then ntk_dnc_seq_bwd runs)."""
+        import os
+        want = self.cluster_k
+        if want is None and os.environ.get("NTK_DNC_CLUSTER_K"):
+            want = int(os.environ["NTK_DNC_CLUSTER_K"])
+        if want == 0:
+            return None
+        key = (B, want)
+        if self._cluster_b is None or self._cluster_b[0] != key:
+            k, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+            rc = _lib.lib().ntk_dnc_cluster_bwd_plan(B, self.N, self.W, self.R, self.Wn, self.hid, self.O, int(want or 0),
+                                                     ctypes.byref(k), ctypes.byref(nbytes))
+            ws = torch.empty((nbytes.value + 3) // 4, device=self.device, dtype=torch.float32) if rc == 0 and k.value > 1 else None
+            self._cluster_b = (key, k.value if ws is not None else 0, ws)
+        return (self._cluster_b[1], self._cluster_b[2]) if self._cluster_b[1] > 1 else None
+
     def check_cluster(self):
-        """Synchronise and raise if a hand-off of the last cluster launch timed out (tests, end of a benchmark)."""
-        if self._cluster is not None and self._cluster[1] > 1:
-            _lib.check(_lib.lib().ntk_dnc_cluster_status(_P(self._cluster[2]), self._cluster[0][0], self._cluster[1], _lib.stream()),
-                       "ntk_dnc_cluster_status")
+        """Synchronise and raise if a hand-off of the last cluster launches timed out (tests, end of a benchmark)."""
+        for c in (self._cluster, self._cluster_b):
+            if c is not None and c[1] > 1:
+                _lib.check(_lib.lib().ntk_dnc_cluster_status(_P(c[2]), c[0][0], c[1], _lib.stream()), "ntk_dnc_cluster_status")
 
     def _launch_fwd(self, xproj, B, S, st, rec):
         """One sequence-kernel launch over contiguous xproj [B*S, 4*hid] starting from state `st` (not modified):
@@ -308,15 +327,22 @@ class DNC(object):
         def c(t):
             keep.append(t.contiguous())
             return _P(keep[-1])
-        _lib.check(_lib.lib().ntk_dnc_seq_bwd(
-            B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value,
-            _P(WrT), ldkT, _P(WiT), ldhT, _P(self.Wy),
-            c(acc.memory), c(acc.linkage.link), c(acc.usage), c(acc.read_weights), c(acc.write_weights),
-            c(acc.linkage.precedence_weights), _P(hc0),
-            _P(rec["gates"]), _P(rec["c"]), _P(rec["ifc"]), _P(rec["u"]), _P(rec["ww"]), _P(rec["rw"]), _P(rec["cw"]),
-            _P(rec["cr"]), _P(rec["al"]), _P(rec["p"]), _P(rec["fwd"]), _P(rec["bwd"]), _P(rec["M"]), _P(rec["L"]),
-            _P(rec["ypre"]), _P(dout), _P(gM), _P(gL), _P(dgates), _P(dxi), _P(dypre),
-            _P(gcarry) if gcarry is not None else None, 1 if carry_in else 0, _lib.stream()), "ntk_dnc_seq_bwd")
+        recs = (_P(rec["gates"]), _P(rec["c"]), _P(rec["ifc"]), _P(rec["u"]), _P(rec["ww"]), _P(rec["rw"]), _P(rec["cw"]),
+                _P(rec["cr"]), _P(rec["al"]), _P(rec["p"]), _P(rec["fwd"]), _P(rec["bwd"]), _P(rec["M"]), _P(rec["L"]),
+                _P(rec["ypre"]), _P(dout), _P(gM), _P(gL), _P(dgates), _P(dxi), _P(dypre),
+                _P(gcarry) if gcarry is not None else None, 1 if carry_in else 0)
+        state0 = (c(acc.memory), c(acc.linkage.link), c(acc.usage), c(acc.read_weights), c(acc.write_weights),
+                  c(acc.linkage.precedence_weights), _P(hc0))
+        plan = self._cluster_bwd_plan(B)
+        self.last_cluster_bwd_k = plan[0] if plan else 1
+        if plan:
+            _lib.check(_lib.lib().ntk_dnc_cluster_bwd(
+                B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value, plan[0],
+                _P(WrT), ldkT, _P(self.Wi), _P(self.Wy), *state0, *recs, _P(plan[1]), _lib.stream()), "ntk_dnc_cluster_bwd")
+        else:
+            _lib.check(_lib.lib().ntk_dnc_seq_bwd(
+                B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value,
+                _P(WrT), ldkT, _P(WiT), ldhT, _P(self.Wy), *state0, *recs, _lib.stream()), "ntk_dnc_seq_bwd")
         return dgates, dxi, dypre
 
     def _weight_grads(self, X2, rec, dgates, dxi, dypre, BS, accumulate):

@@ -413,3 +413,62 @@ def test_dnc_cluster_forward_full_length_is_deterministic(cuda):
     o5, _ = core.run_sequence(x[:, 5:6].contiguous())
     core.check_cluster()
     assert torch.equal(o5[:, 0], o1[:, 5])
+
+
+@pytest.mark.parametrize("name,N,W,R,hid,S,B,ks", CLUSTER_CASES, ids=[c[0] for c in CLUSTER_CASES])
+def test_dnc_cluster_bptt_equals_single_workgroup_kernel(cuda, name, N, W, R, hid, S, B, ks):
+    """Cluster BPTT (d(link) rows LDS resident and split k ways, d(memory) in registers, two exchanges per step) against
+    the one-workgroup-per-sequence BPTT kernel (itself checked against torch autograd above) on the same recorded
+    sequence: every gradient tensor to 1e-4 of its largest entry, bitwise identical across two runs (no float
+    atomics), also when the sequence is cut into BPTT segments (gradients carried between launches)."""
+    from ntmtrack import dnc as G
+    Din, O = 12, 2
+    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=1, hidden_size=hid, clip_value=20.0)
+    rng = np.random.default_rng(41)
+    p = D.init_params(cfg, rng)
+    for kk in p:
+        if kk.endswith("/b") or kk.endswith("b_gates"):
+            p[kk] = rng.uniform(-0.3, 0.3, size=p[kk].shape).astype(np.float32)
+        if kk.startswith("memory_access/") and kk.endswith("/w"):
+            p[kk] = (p[kk] * 4).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((S, B, Din)).astype(np.float32)).to(cuda)
+    dout = torch.from_numpy(rng.standard_normal((B, S, O)).astype(np.float32)).to(cuda)
+    st0 = _random_state(cfg, B, rng)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(cuda)
+    a0 = st0.access_state
+    gst = G.DNCState(t(st0.access_output), G.AccessState(t(a0.memory), t(a0.read_weights), t(a0.write_weights),
+                     G.TemporalLinkageState(t(a0.linkage.link), t(a0.linkage.precedence_weights)), t(a0.usage)),
+                     G.LSTMState(t(st0.controller_state.hidden), t(st0.controller_state.cell)))
+
+    def run(k, segment=None):
+        core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, 20.0, device=cuda)
+        core.load_state_dict({kk: torch.from_numpy(v) for kk, v in p.items()})
+        core.cluster_k = k
+        core.bptt_segment = segment
+        core.run_sequence(x, gst, record=True)
+        grads = core.backward_sequence(core.last_X, dout)
+        core.check_cluster()
+        torch.cuda.synchronize()
+        return {kk: v.clone() for kk, v in grads.items()}, core.last_cluster_bwd_k
+
+    ref, used = run(0)
+    assert used == 1
+    tried = 0
+    for k in ks:
+        got, used = run(k)
+        if used != k:
+            assert used == 1
+            continue
+        tried += 1
+        for kk in sorted(ref):
+            a_, b_ = got[kk].cpu().numpy(), ref[kk].cpu().numpy()
+            err = float(np.max(np.abs(a_ - b_)) / (np.max(np.abs(b_)) + 1e-30))
+            assert err < 1e-4, "%s k=%d: %.3e" % (kk, k, err)
+        again, _ = run(k)
+        assert all(torch.equal(again[kk], got[kk]) for kk in got), "cluster BPTT is not bitwise reproducible (k=%d)" % k
+        seg, _ = run(k, segment=max(2, S // 2))
+        for kk in sorted(ref):
+            a_, b_ = seg[kk].cpu().numpy(), got[kk].cpu().numpy()
+            err = float(np.max(np.abs(a_ - b_)) / (np.max(np.abs(b_)) + 1e-30))
+            assert err < 2e-5, "segmented %s k=%d: %.3e" % (kk, k, err)
+    assert tried >= 1
