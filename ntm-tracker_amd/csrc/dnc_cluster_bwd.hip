@@ -23,11 +23,26 @@
 #include "dnc_cluster.h"
 #include <stdlib.h>
 
+// Diagnostic build only (-DNTK_CL_PROF): see dnc_cluster_fwd.hip
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_clb_prof[32];
+#define CLB_STAMP(i)                                                                  \
+    do {                                                                              \
+        if (blockIdx.x == 0 && tid == 0) {                                            \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+            prof_acc[i] += now_ - prof_last;                                          \
+            prof_last = now_;                                                         \
+        }                                                                             \
+    } while (0)
+#else
+#define CLB_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 struct DncClBwdLds {
     int part, CS, GL, LT, I, DX, WW, WWp, U, Up, Pp, CW, AL, SIMw, DWW, DCW, DA, gP, DPp, gU, gUn, NU, KEY, RANK,
-        RWp, gRW, G, DRWp, DSIM, SIMr, GZ, DR, DHC, DG, gC, SC, total;
+        RWp, RWt, gRW, G, DRWp, DSIM, SIMr, GZ, DR, DHC, DG, gC, SC, total;
 };
 
 struct DncClBwdGeo {
@@ -74,7 +89,7 @@ constexpr __host__ __device__ DncClBwdLds dnc_cl_bwd_lds(const DncClusterCfg& c,
     L.WW = take(N); L.WWp = take(N); L.U = take(N); L.Up = take(N); L.Pp = take(N); L.CW = take(N); L.AL = take(N);
     L.SIMw = take(N); L.DWW = take(N); L.DCW = take(N); L.DA = take(N); L.gP = take(N); L.DPp = take(N); L.gU = take(N);
     L.gUn = take(N); L.NU = take(N); L.KEY = take(2 * N); L.RANK = take(N);
-    L.RWp = take(RN); L.gRW = take(RN); L.G = take(RN); L.DRWp = take(RN); L.DSIM = take(RN); L.SIMr = take(RN);
+    L.RWp = take(RN); L.RWt = take(RN); L.gRW = take(RN); L.G = take(RN); L.DRWp = take(RN); L.DSIM = take(RN); L.SIMr = take(RN);
     L.GZ = take(q.ldkT); L.DR = take(c.R * c.W); L.DHC = take(c.hid); L.DG = take(4 * c.upk); L.gC = take(c.upk);
     L.SC = take(128);
     L.total = o;
@@ -118,7 +133,7 @@ constexpr int MAXQ = 8;       // memory rows per 16-lane group (N <= 256)
     float* sDPp = smem + L.DPp; float* sgU = smem + L.gU; float* sgUn = smem + L.gUn; float* sNU = smem + L.NU;               \
     unsigned long long* sKEY = reinterpret_cast<unsigned long long*>(smem + L.KEY);                                          \
     int* sRank = reinterpret_cast<int*>(smem + L.RANK);                                                                       \
-    float* sRWp = smem + L.RWp; float* sgRW = smem + L.gRW; float* sG = smem + L.G; float* sDRWp = smem + L.DRWp;             \
+    float* sRWp = smem + L.RWp; float* sRWt = smem + L.RWt; float* sgRW = smem + L.gRW; float* sG = smem + L.G; float* sDRWp = smem + L.DRWp;             \
     float* sDSIM = smem + L.DSIM; float* sSIMr = smem + L.SIMr;                                                               \
     float* sGZ = smem + L.GZ; float* sDR = smem + L.DR; float* sDHC = smem + L.DHC; float* sDG = smem + L.DG;                 \
     float* sgC = smem + L.gC; float* sSC = smem + L.SC; int* sAbort = reinterpret_cast<int*>(sSC + 120);                       \
@@ -126,7 +141,7 @@ constexpr int MAXQ = 8;       // memory rows per 16-lane group (N <= 256)
     (void)k; (void)K; (void)IP; (void)RWd; (void)N4; (void)W4; (void)u1; (void)nU; (void)RN; (void)sPart; (void)sCS; (void)sGL;\
     (void)sLt; (void)sI; (void)sDX; (void)sWW; (void)sWWp; (void)sU; (void)sUp; (void)sPp; (void)sCW; (void)sAL; (void)sSIMw; \
     (void)sDWW; (void)sDCW; (void)sDA; (void)sgP; (void)sDPp; (void)sgU; (void)sgUn; (void)sNU; (void)sKEY; (void)sRank;      \
-    (void)sRWp; (void)sgRW; (void)sG; (void)sDRWp; (void)sDSIM; (void)sSIMr; (void)sGZ; (void)sDR; (void)sDHC; (void)sDG;     \
+    (void)sRWp; (void)sRWt; (void)sgRW; (void)sG; (void)sDRWp; (void)sDSIM; (void)sSIMr; (void)sGZ; (void)sDR; (void)sDHC; (void)sDG;     \
     (void)sgC; (void)sAbort; (void)sGL4; (void)sLt4; (void)row0; (void)u0
 
 template <bool FIX>
@@ -186,6 +201,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         }
     }
     __syncthreads();
+#ifdef NTK_CL_PROF
+    unsigned long long prof_acc[20] = {0}, prof_last = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int t = S - 1; t >= 0; --t) {
         ArgsK ak = ak0;
@@ -201,7 +219,8 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         }
         CL_BWD_VIEWS();
         const float clipv = a.clip;
-        const int NQ = Q.NQ;
+        int NQ = Q.NQ;
+        if constexpr (FIX) asm volatile("" : "+s"(NQ));     // opaque: the per-row guards stay branches, so the scheduler cannot hoist all rows' loads at once
         const int slot0 = Q.slot0, slot1 = Q.slot1;
         float* mb0 = a.mbox + (size_t)b * 2 * k * ((size_t)slot0 + slot1);        // [parity][g][slot0]
         float* mb1 = mb0 + (size_t)2 * k * slot0;
@@ -220,25 +239,36 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         const float* gFV = a.rec_fwd + bt * RN;
         const float* gBV = a.rec_bwd + bt * RN;
 
+        CLB_STAMP(0);
         // ------------------------------------------------------------ load this step's records
-        for (int c = tid; c < IP; c += CT) { sI[c] = a.rec_ifc[bt * IP + c]; sDX[c] = 0.f; }
+        //   (the t == 0 / t > 0 choice is made on the POINTERS: a per-element select makes hipcc branch around every load)
         {
+            const float* p_ifc = a.rec_ifc + bt * IP;
+            const float* p_ww = a.rec_ww + bt * N; const float* p_u = a.rec_u + bt * N; const float* p_cw = a.rec_cw + bt * N;
+            const float* p_al = a.rec_al + bt * N;
+            const float* p_wwp = (t > 0) ? a.rec_ww + (bt - 1) * N : a.ww0 + (size_t)b * N;
+            const float* p_up = (t > 0) ? a.rec_u + (bt - 1) * N : a.usage0 + (size_t)b * N;
+            const float* p_pp = (t > 0) ? a.rec_p + (bt - 1) * N : a.prec0 + (size_t)b * N;
+            const float* p_rwp = (t > 0) ? a.rec_rw + (bt - 1) * RN : a.rw0 + (size_t)b * RN;
+            for (int c = tid; c < IP; c += CT) { sI[c] = p_ifc[c]; sDX[c] = 0.f; }
+            for (int i = tid; i < RN; i += CT) { sRWp[i] = p_rwp[i]; sRWt[i] = gRWt[i]; }
+            {
 #pragma clang fp contract(off)
-            for (int n = tid; n < N; n += CT) {
-                sWW[n] = a.rec_ww[bt * N + n];
-                const float u = a.rec_u[bt * N + n];
-                sU[n] = u;
-                sCW[n] = a.rec_cw[bt * N + n];
-                sAL[n] = a.rec_al[bt * N + n];
-                sWWp[n] = (t > 0) ? a.rec_ww[(bt - 1) * N + n] : a.ww0[(size_t)b * N + n];
-                sUp[n] = (t > 0) ? a.rec_u[(bt - 1) * N + n] : a.usage0[(size_t)b * N + n];
-                sPp[n] = (t > 0) ? a.rec_p[(bt - 1) * N + n] : a.prec0[(size_t)b * N + n];
-                const float nu = 1.0f - (EPS + (1.0f - EPS) * u);                 // exactly the forward kernel's expression
-                sNU[n] = nu;
-                sKEY[n] = ((unsigned long long)__float_as_uint(nu) << 32) | (unsigned)(0xFFFF - n);
+                for (int n = tid; n < N; n += CT) {
+                    const float u = p_u[n];
+                    sWW[n] = p_ww[n];
+                    sU[n] = u;
+                    sCW[n] = p_cw[n];
+                    sAL[n] = p_al[n];
+                    sWWp[n] = p_wwp[n];
+                    sUp[n] = p_up[n];
+                    sPp[n] = p_pp[n];
+                    const float nu = 1.0f - (EPS + (1.0f - EPS) * u);             // exactly the forward kernel's expression
+                    sNU[n] = nu;
+                    sKEY[n] = ((unsigned long long)__float_as_uint(nu) << 32) | (unsigned)(0xFFFF - n);
+                }
             }
         }
-        for (int i = tid; i < RN; i += CT) sRWp[i] = (t > 0) ? a.rec_rw[(bt - 1) * RN + i] : a.rw0[(size_t)b * RN + i];
         if (tid < 64) sSC[tid] = 0.f;
         if (tid < C.OP) {                         // B1: output clip + linear
             float gy = 0.f;
@@ -250,6 +280,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             if (g == 0) a.dypre[bt * C.OP + tid] = gy;
         }
         __syncthreads();
+        CLB_STAMP(1);
         for (int kk = tid; kk < C.Ky; kk += CT) {
             float s = 0.f;
             for (int o = 0; o < C.O; ++o) s += a.Wy[(size_t)kk * C.OP + o] * sSC[32 + o];
@@ -284,6 +315,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             sRank[n] = rk;
         }
 
+        CLB_STAMP(2);
         // ------------------------------------------------------------ B2: pass 1 over M_t (registers): d(rw) from the reads, read-key scores
         float nmr[MAXQ];                                       // |M_t[n]| of the rows of this group
         {
@@ -317,10 +349,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                         }
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set of the unrolled loop small
+                if (FIX || q == 3) __builtin_amdgcn_sched_barrier(0);      // two halves: bounds the live set of the unrolled loop
             }
         }
         __syncthreads();
+        CLB_STAMP(3);
         // ------------------------------------------------------------ B3: read-weight mix, read-content softmax (wave i = head i)
         if (wave < R) {
             const int i = wave;
@@ -351,6 +384,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             }
         }
         __syncthreads();
+        CLB_STAMP(4);
         // ------------------------------------------------------------ B4: pass 2 over M_t: d(M_t) (registers) and d(read keys)
         f32x4 accK[4];
         float accNk[4];
@@ -386,7 +420,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                             const float dD = -dsim * dot / (D * D);
                             dnm += dD * krn[i];
                             if (gl == 0) accNk[i] += dD * nm;
-                            const float rwn = gRWt[i * N + n];
+                            const float rwn = sRWt[i * N + n];
                             gq += rwn * dr[i] + ddot * kr[i];
                             accK[i] += ddot * m;
                         }
@@ -394,7 +428,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     gq += (dnm / nm) * m;
                     gMr[q] = gq;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (FIX || q == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // column sums of B4 (d read keys): fold the four 16-lane groups of the wave, park per wave (summed at the end)
@@ -414,6 +448,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                 for (int i = 0; i < 4; ++i) sSC[72 + wave * 4 + i] = accNk[i];        // sSC[72 .. 72 + 8 * 4): d|kr_i| per wave
             }
         }
+        CLB_STAMP(5);
         // M_t is dead from here: its registers take the memory rows of step t-1 (requested now, first used in B7)
         {
             const float* Mpg = (t > 0) ? a.rec_M + (bt - 1) * N * W : a.mem0 + (size_t)b * N * W;
@@ -446,31 +481,43 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     if (i < R) { rwpb[i] = *reinterpret_cast<const f32x4*>(sRWp + i * N + b0); dbb[i] = rm0[i] * *reinterpret_cast<const f32x4*>(sG + i * N + b0); }
             }
             float* slot = mb0 + ((size_t)par * k + g) * slot0;            // [rowRW R x NR | rowWW NR | colRW R x N | colWW N | colP N]
-#pragma unroll 1
-            for (int r = wave; r < NR; r += CW) {
-                const int ra = row0 + r;
-                const float wwa = sWW[ra];
-                float rowWW = 0.f;
-                if (colok) {
-                    const int ph = r * N4 + (lane ^ (r & 7));
-                    f32x4 gq = sGL4[ph];
-                    const f32x4 lp = reinterpret_cast<const f32x4*>(Lpg + (size_t)r * N)[lane];
+            for (int rb = wave; rb < NR; rb += 4 * CW) {          // four rows of this wave per batch: their L_{t-1} loads go first
+                f32x4 lpv[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < R) gq += (rm1[i] * sG[i * N + ra]) * rwpb[i] + sRWp[i * N + ra] * dbb[i];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (b0 + e == ra) gq[e] = 0.f;   // the diagonal of L_t is forced to 0
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rowWW += gq[e] * (ppb[e] - lp[e]);
-                    colWW -= gq * lp;
-                    colP += wwa * gq;
-                    f32x4 gn;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gn[e] = (1.0f - wwa - wwb[e]) * gq[e];
-                    sGL4[ph] = gn;
+                for (int u = 0; u < 4; ++u) {
+                    const int r = rb + u * CW;
+                    lpv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (colok && r < NR) lpv[u] = reinterpret_cast<const f32x4*>(Lpg + (size_t)r * N)[lane];
                 }
-                rowWW = wave_sum(rowWW);
-                if (lane == 0) cl_store(slot + R * NR + r, rowWW);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = rb + u * CW;
+                    if (r < NR) {
+                        const int ra = row0 + r;
+                        const float wwa = sWW[ra];
+                        float rowWW = 0.f;
+                        if (colok) {
+                            const int ph = r * N4 + (lane ^ (r & 7));
+                            f32x4 gq = sGL4[ph];
+                            const f32x4 lp = lpv[u];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (i < R) gq += (rm1[i] * sG[i * N + ra]) * rwpb[i] + sRWp[i * N + ra] * dbb[i];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (b0 + e == ra) gq[e] = 0.f;   // the diagonal of L_t is forced to 0
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rowWW += gq[e] * (ppb[e] - lp[e]);
+                            colWW -= gq * lp;
+                            colP += wwa * gq;
+                            f32x4 gn;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) gn[e] = (1.0f - wwa - wwb[e]) * gq[e];
+                            sGL4[ph] = gn;
+                        }
+                        rowWW = wave_sum(rowWW);
+                        if (lane == 0) cl_store(slot + R * NR + r, rowWW);
+                    }
+                }
             }
             if (colok) {
                 *reinterpret_cast<f32x4*>(sPart + (wave * 2 + 0) * N + b0) = colWW;
@@ -485,6 +532,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                 cl_store(slot + (R + 1) * NR + R * N + idx, s);
             }
             __syncthreads();
+        CLB_STAMP(6);
             // (c) the two read-weight products on the 4x4x1 MFMA:
             //     column sums  colRW[i][b] = sum_a dF_i[a] L_t[a][b]   (over the own rows: partial)
             //     row sums     rowRW[i][a] = sum_b dB_i[b] L_t[a][b]   (complete)
@@ -548,7 +596,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             }
             cl_publish(fl0 + g, epoch, tid);
         }
+        CLB_STAMP(7);
         if (!cl_wait(fl0, epoch, k, a.err, sAbort, t_start, tid)) return;
+        CLB_STAMP(8);
         {   // consume exchange 0: d(rw_{t-1}) (link part), d(ww_t) (link part), d(precedence_{t-1}) (link part)
             const float* base = mb0 + (size_t)par * k * slot0;
             for (int idx = tid; idx < RN; idx += CT) {
@@ -577,6 +627,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                 sDPp[n] = sp;
             }
         }
+        CLB_STAMP(9);
         // ------------------------------------------------------------ B6: precedence (wave 0 computes the two scalars)
         if (wave == 0) {
             float sw = 0.f, t1 = 0.f;
@@ -590,6 +641,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             sDWW[n] += sgP[n] - sSC[17];
         }
         __syncthreads();
+        CLB_STAMP(10);
         // ------------------------------------------------------------ B7: write backward over (dM, M_{t-1}); write-key scores
         f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accV = accE;
         float nmw[MAXQ];
@@ -628,10 +680,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                         sSIMw[n] = dot / (nkw * nm + EPS);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (FIX || q == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
+        CLB_STAMP(11);
         // ------------------------------------------------------------ B8: write-weight mix (access.py:252-257)
         {
             const float ga = sI[C.oAg], gw = sI[C.oWg];
@@ -702,6 +755,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             const float bw = sI[C.oBw];
             if (lane == 0) sDX[C.oBw] = dbeta * (1.0f - expf(-bw));
         }
+        CLB_STAMP(12);
         // ------------------------------------------------------------ B10b: content part of d(M_{t-1}) (registers), d(write key)
         f32x4 accKw = {0.f, 0.f, 0.f, 0.f};
         float accNkw = 0.f;
@@ -724,7 +778,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     gMr[q] += ddot * kp + (dD * nk / nm) * mp;
                     accKw += ddot * mp;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (FIX || q == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ------------------------------------------------------------ B11: usage backward (addressing.py:342-374)
@@ -807,6 +861,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         __syncthreads();
         if (g == 0) for (int c = tid; c < IP; c += CT) a.dxi[bt * IP + c] = sDX[c];
 
+        CLB_STAMP(13);
         // ------------------------------------------------------------ B14: d(clipped h) of the own units += d(interface) . Wi^T
         //   Wi is [unit][IP]: the own units' rows are contiguous -- thread = (own unit, slice of the float4 columns)
         if (tid < Q.nslH * upk) {
@@ -830,7 +885,8 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             const f32x4 gg = reinterpret_cast<const f32x4*>(a.rec_gates)[bt * hid + u];
             const float gi = gg[0], gj = gg[1], gf = gg[2], go = gg[3];
             const float c2 = a.rec_c[bt * hid + u];
-            const float cprev = (t > 0) ? dnc_clip(a.rec_c[(bt - 1) * hid + u], clipv) : a.hc0[(size_t)b * 2 * hid + hid + u];
+            const float* p_cprev = (t > 0) ? a.rec_c + (bt - 1) * hid : a.hc0 + (size_t)b * 2 * hid + hid;
+            const float cprev = dnc_clip(p_cprev[u], clipv);      // the recorded cell is pre-clip; the carried state was clipped
             const float tc = tanhf(c2);
             const float h2 = tc * go;
             const float dh2 = (clipv <= 0.f || fabsf(h2) < clipv) ? dh : 0.f;
@@ -846,6 +902,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             reinterpret_cast<f32x4*>(a.dgates)[bt * hid + u] = dg;
         }
         __syncthreads();
+        CLB_STAMP(14);
         // ------------------------------------------------------------ B16: partial d[reads_prev ; h_prev] over the own gate columns
         {
             const int kg4 = Q.kg4, nrow = 4 * nU;
@@ -865,7 +922,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             }
             cl_publish(fl1 + g, epoch, tid);
         }
+        CLB_STAMP(15);
         if (!cl_wait(fl1, epoch, k, a.err, sAbort, t_start, tid)) return;
+        CLB_STAMP(16);
         {
             const float* base = mb1 + (size_t)par * k * slot1;
             for (int kk = tid; kk < K; kk += CT) {
@@ -879,7 +938,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             }
         }
         __syncthreads();
+        CLB_STAMP(17);
     }
+#ifdef NTK_CL_PROF
+    if (blockIdx.x == 0 && tid0 == 0) for (int i = 0; i < 20; ++i) g_clb_prof[i] = prof_acc[i];
+#endif
 
     // ---- carried gradients out (segmented BPTT); d(memory) / d(link) scratch updated in place
     {
@@ -913,6 +976,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
+#ifdef NTK_CL_PROF
+extern "C" int ntk_dnc_cluster_bwd_prof(unsigned long long* out20) {
+    return hipMemcpyFromSymbol(out20, HIP_SYMBOL(g_clb_prof), 20 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#endif
 static size_t dnc_cluster_ctrl_bytes(int B, int k) { return (((size_t)B * 2 * k + 1) * sizeof(unsigned) + 255) & ~(size_t)255; }
 
 // cluster size for the backward pass (0 = outside its range): the forward constraints plus N <= 256 (d(memory) is
@@ -1002,7 +1070,7 @@ extern "C" int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, in
     }
     hipError_t e = hipMemsetAsync(workspace, 0, ctrl, (hipStream_t)stream);
     NTK_REQUIRE(e == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    if (dnc_cluster_is_fix(a.c) && getenv("NTK_DNC_BWD_FIX")) dnc_cluster_bwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
+    if (dnc_cluster_is_fix(a.c) && !getenv("NTK_DNC_BWD_GENERIC")) dnc_cluster_bwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     else dnc_cluster_bwd_kernel<false><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     NTK_CHECK_LAUNCH("ntk_dnc_cluster_bwd");
     return NTK_OK;

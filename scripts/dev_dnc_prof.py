@@ -26,3 +26,22 @@ tot = float(sum(buf))
 print("cluster fwd N=%d W=%d B=%d S=%d k=%d record=%s: %.0f cycles/step (workgroup 0, stamped build)" % (N, W, B, S, core.last_cluster_k, record, tot / S))
 for i in order:
     print("  %-32s %8.0f cyc/step  %5.1f %%" % (names[i], buf[i] / S, 100.0 * buf[i] / tot))
+
+# ---- backward
+if record:
+    dout = torch.randn((B, S, 2), device=dev)
+    for _ in range(2):
+        core.run_sequence(x, record=True)
+        core.backward_sequence(core.last_X, dout)
+    torch.cuda.synchronize(); core.check_cluster()
+    fnb = L.ntk_dnc_cluster_bwd_prof
+    fnb.restype = ctypes.c_int
+    bb = (ctypes.c_ulonglong * 20)()
+    assert fnb(bb) == 0
+    nb = ["top (prev consume tail)", "load records+B1", "S1 Wy^T dy, norms, rank", "rank sum + B2", "B3 head reductions", "B4 dM pass + col fold",
+          "reload M + B5ab link elementwise", "B5c MFMA + publish", "X0 wait", "X0 consume", "B6 precedence", "B7 write bwd pass", "B8/B9 alloc bwd",
+          "B10b/B11/colsums/dxi", "B14/B15 dh + LSTM bwd", "B16 dz partial + publish", "X1 wait", "X1 consume"]
+    totb = float(sum(bb))
+    print("cluster bwd: %.0f cycles/step (workgroup 0, stamped build)" % (totb / S))
+    for i, nm in enumerate(nb):
+        print("  %-36s %8.0f cyc/step  %5.1f %%" % (nm, bb[i] / S, 100.0 * bb[i] / totb))
