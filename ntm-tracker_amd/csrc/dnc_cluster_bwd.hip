@@ -204,6 +204,57 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
 #ifdef NTK_CL_PROF
     unsigned long long prof_acc[20] = {0}, prof_last = __builtin_amdgcn_s_memtime();
 #endif
+    // the small per-step records are requested one step ahead (they stream from HBM: a step's own loads would sit on
+    // its critical path): pf_* hold step t's values when step t starts
+    float pf_ifc = 0.f, pf_rwp[2] = {0.f, 0.f}, pf_rwt[2] = {0.f, 0.f}, pf_ww = 0.f, pf_u = 0.f, pf_cw = 0.f, pf_al = 0.f,
+          pf_wwp = 0.f, pf_up = 0.f, pf_pp = 0.f;
+    float pf_ypre = 0.f, pf_dout = 0.f;                       // B1: threads tid < O
+    float pf_cr[4] = {0.f, 0.f, 0.f, 0.f}, pf_fv[4] = {0.f, 0.f, 0.f, 0.f}, pf_bv[4] = {0.f, 0.f, 0.f, 0.f};   // B3: wave i < R, slots lane + 64 j
+    f32x4 pf_gates = {0.f, 0.f, 0.f, 0.f};                    // B15: threads tid < nU
+    float pf_c = 0.f, pf_cprev = 0.f;
+    auto prefetch_records = [&](auto ap, int t, int N, int RN, int IP) {      // ap: by-value block or kernarg (address space 4) pointer
+        const size_t bt = (size_t)b * S + t;
+        const float* p_wwp = (t > 0) ? ap->rec_ww + (bt - 1) * N : ap->ww0 + (size_t)b * N;
+        const float* p_up = (t > 0) ? ap->rec_u + (bt - 1) * N : ap->usage0 + (size_t)b * N;
+        const float* p_pp = (t > 0) ? ap->rec_p + (bt - 1) * N : ap->prec0 + (size_t)b * N;
+        const float* p_rwp = (t > 0) ? ap->rec_rw + (bt - 1) * RN : ap->rw0 + (size_t)b * RN;
+        if (tid0 < IP) pf_ifc = ap->rec_ifc[bt * IP + tid0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid0 + u * CT;
+            if (i < RN) { pf_rwp[u] = p_rwp[i]; pf_rwt[u] = ap->rec_rw[bt * RN + i]; }
+        }
+        if (tid0 < N) {
+            pf_ww = ap->rec_ww[bt * N + tid0]; pf_u = ap->rec_u[bt * N + tid0]; pf_cw = ap->rec_cw[bt * N + tid0];
+            pf_al = ap->rec_al[bt * N + tid0]; pf_wwp = p_wwp[tid0]; pf_up = p_up[tid0]; pf_pp = p_pp[tid0];
+        }
+        const int O_ = FIX ? kDncClusterFixCfg.O : ap->c.O, R_ = RN / N;
+        if (tid0 < O_) { pf_ypre = ap->rec_ypre[bt * O_ + tid0]; pf_dout = ap->dout[bt * O_ + tid0]; }
+        if ((tid0 >> 6) < R_) {
+            const int i = tid0 >> 6, ln = tid0 & 63;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ln + 64 * j;
+                if (n < N) { pf_cr[j] = ap->rec_cr[bt * RN + i * N + n]; pf_fv[j] = ap->rec_fwd[bt * RN + i * N + n]; pf_bv[j] = ap->rec_bwd[bt * RN + i * N + n]; }
+            }
+        }
+    };
+    auto prefetch_gates = [&](auto ap, int t) {               // B15's records of step t (own hidden units)
+        const size_t bt = (size_t)b * S + t;
+        const int hid_ = FIX ? kDncClusterFixCfg.hid : ap->c.hid, upk_ = FIX ? kDncClusterFixCfg.upk : ap->c.upk;
+        const int u0_ = min(hid_, g * upk_), nU_ = min(hid_, u0_ + upk_) - u0_;
+        if (tid0 < nU_) {
+            const int u = u0_ + tid0;
+            const float* p_cprev = (t > 0) ? ap->rec_c + (bt - 1) * hid_ : ap->hc0 + (size_t)b * 2 * hid_ + hid_;
+            pf_gates = reinterpret_cast<const f32x4*>(ap->rec_gates)[bt * hid_ + u];
+            pf_c = ap->rec_c[bt * hid_ + u];
+            pf_cprev = p_cprev[u];
+        }
+    };
+    {
+        const DncClusterCfg C0 = FIX ? kDncClusterFixCfg : a0.c;
+        prefetch_records(&a0, S - 1, C0.N, C0.R * C0.N, C0.IP);
+    }
 
     for (int t = S - 1; t >= 0; --t) {
         ArgsK ak = ak0;
@@ -236,46 +287,37 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         const float* Ltg = a.rec_L + (bt * N + row0) * N;
         const float* Lpg = (t > 0) ? a.rec_L + ((bt - 1) * N + row0) * N : a.link0 + ((size_t)b * N + row0) * N;
         const float* gRWt = a.rec_rw + bt * RN;          // single-use records are read where they are consumed
-        const float* gFV = a.rec_fwd + bt * RN;
-        const float* gBV = a.rec_bwd + bt * RN;
 
         CLB_STAMP(0);
-        // ------------------------------------------------------------ load this step's records
-        //   (the t == 0 / t > 0 choice is made on the POINTERS: a per-element select makes hipcc branch around every load)
+        // ------------------------------------------------------------ this step's records: registers -> LDS; next step's requested
         {
-            const float* p_ifc = a.rec_ifc + bt * IP;
-            const float* p_ww = a.rec_ww + bt * N; const float* p_u = a.rec_u + bt * N; const float* p_cw = a.rec_cw + bt * N;
-            const float* p_al = a.rec_al + bt * N;
-            const float* p_wwp = (t > 0) ? a.rec_ww + (bt - 1) * N : a.ww0 + (size_t)b * N;
-            const float* p_up = (t > 0) ? a.rec_u + (bt - 1) * N : a.usage0 + (size_t)b * N;
-            const float* p_pp = (t > 0) ? a.rec_p + (bt - 1) * N : a.prec0 + (size_t)b * N;
-            const float* p_rwp = (t > 0) ? a.rec_rw + (bt - 1) * RN : a.rw0 + (size_t)b * RN;
-            for (int c = tid; c < IP; c += CT) { sI[c] = p_ifc[c]; sDX[c] = 0.f; }
-            for (int i = tid; i < RN; i += CT) { sRWp[i] = p_rwp[i]; sRWt[i] = gRWt[i]; }
+            if (tid < IP) { sI[tid] = pf_ifc; sDX[tid] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + u * CT;
+                if (i < RN) { sRWp[i] = pf_rwp[u]; sRWt[i] = pf_rwt[u]; }
+            }
             {
 #pragma clang fp contract(off)
-                for (int n = tid; n < N; n += CT) {
-                    const float u = p_u[n];
-                    sWW[n] = p_ww[n];
-                    sU[n] = u;
-                    sCW[n] = p_cw[n];
-                    sAL[n] = p_al[n];
-                    sWWp[n] = p_wwp[n];
-                    sUp[n] = p_up[n];
-                    sPp[n] = p_pp[n];
+                if (tid < N) {
+                    const float u = pf_u;
+                    sWW[tid] = pf_ww;
+                    sU[tid] = u;
+                    sCW[tid] = pf_cw;
+                    sAL[tid] = pf_al;
+                    sWWp[tid] = pf_wwp;
+                    sUp[tid] = pf_up;
+                    sPp[tid] = pf_pp;
                     const float nu = 1.0f - (EPS + (1.0f - EPS) * u);             // exactly the forward kernel's expression
-                    sNU[n] = nu;
-                    sKEY[n] = ((unsigned long long)__float_as_uint(nu) << 32) | (unsigned)(0xFFFF - n);
+                    sNU[tid] = nu;
+                    sKEY[tid] = ((unsigned long long)__float_as_uint(nu) << 32) | (unsigned)(0xFFFF - tid);
                 }
             }
         }
         if (tid < 64) sSC[tid] = 0.f;
         if (tid < C.OP) {                         // B1: output clip + linear
             float gy = 0.f;
-            if (tid < C.O) {
-                const float pre = a.rec_ypre[bt * C.O + tid];
-                gy = (clipv <= 0.f || fabsf(pre) < clipv) ? a.dout[bt * C.O + tid] : 0.f;
-            }
+            if (tid < C.O) gy = (clipv <= 0.f || fabsf(pf_ypre) < clipv) ? pf_dout : 0.f;
             sSC[32 + tid] = gy;
             if (g == 0) a.dypre[bt * C.OP + tid] = gy;
         }
@@ -317,6 +359,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
 
         CLB_STAMP(2);
         // ------------------------------------------------------------ B2: pass 1 over M_t (registers): d(rw) from the reads, read-key scores
+        // B15's records (gates, cells of the own units) of THIS step are requested here: the vector-memory counter is in
+        // order, so any later load waits for earlier ones too -- B2..B4 touch only registers and LDS while these land
+        prefetch_gates(ak, t);
         float nmr[MAXQ];                                       // |M_t[n]| of the rows of this group
         {
             f32x4 dr[4], kr[4];
@@ -358,21 +403,28 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         if (wave < R) {
             const int i = wave;
             const float* rm = sI + C.oRm + i * 3;              // [backward, forward, content] (access.py:283-289)
-            const float* crg = a.rec_cr + bt * RN + i * N;
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, s1 = 0.f;
-            for (int n = lane; n < N; n += 64) {
-                const float gg = sG[i * N + n], cr = crg[n];
-                p0 += gg * gBV[i * N + n]; p1 += gg * gFV[i * N + n]; p2 += gg * cr;
-                s1 += cr * (rm[2] * gg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = lane + 64 * j;
+                if (n < N) {
+                    const float gg = sG[i * N + n], cr = pf_cr[j];
+                    p0 += gg * pf_bv[j]; p1 += gg * pf_fv[j]; p2 += gg * cr;
+                    s1 += cr * (rm[2] * gg);
+                }
             }
             p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2); s1 = wave_sum(s1);
             const float br = sI[C.oBr + i];
             float dbeta = 0.f;
-            for (int n = lane; n < N; n += 64) {
-                const float gg = sG[i * N + n];
-                const float dscore = crg[n] * (rm[2] * gg - s1);
-                dbeta += dscore * sSIMr[i * N + n];
-                sDSIM[i * N + n] = dscore * br;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = lane + 64 * j;
+                if (n < N) {
+                    const float gg = sG[i * N + n];
+                    const float dscore = pf_cr[j] * (rm[2] * gg - s1);
+                    dbeta += dscore * sSIMr[i * N + n];
+                    sDSIM[i * N + n] = dscore * br;
+                }
             }
             dbeta = wave_sum(dbeta);
             if (lane == 0) {
@@ -458,7 +510,10 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         }
         // ------------------------------------------------------------ B5: link pass over the own rows (dL in LDS, L_t and L_{t-1} records)
         {
-            // (a) the recorded L_t rows go to LDS (operands of the two MFMA products)
+            // (a) the recorded L_t rows go to LDS (operands of the two MFMA products) -- from HBM only on the first step of a
+            //     launch or when a wave owns more than four rows: otherwise the previous iteration left its L_{t-1} rows there
+            const bool tile_kept = (NR <= 4 * CW) && (t != S - 1);
+            if (!tile_kept)
 #pragma unroll 2
             for (int base = tid; base < NR * N4; base += CT) {
                 const int r = FIX ? base / N4 : cl_div(base, C.mg_N4), qq = base - r * N4;
@@ -481,8 +536,8 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     if (i < R) { rwpb[i] = *reinterpret_cast<const f32x4*>(sRWp + i * N + b0); dbb[i] = rm0[i] * *reinterpret_cast<const f32x4*>(sG + i * N + b0); }
             }
             float* slot = mb0 + ((size_t)par * k + g) * slot0;            // [rowRW R x NR | rowWW NR | colRW R x N | colWW N | colP N]
+            f32x4 lpv[4];
             for (int rb = wave; rb < NR; rb += 4 * CW) {          // four rows of this wave per batch: their L_{t-1} loads go first
-                f32x4 lpv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int r = rb + u * CW;
@@ -594,6 +649,13 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                 for (int qq = 0; qq < 2 * strips; ++qq) f += sPart[(qq * NRp + r) * 4 + i];
                 cl_store(slot + idx, f);
             }
+            if (NR <= 4 * CW && colok) {          // L_{t-1} rows (still in registers) become the next iteration's L_t tile
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = wave + u * CW;
+                    if (r < NR) sLt4[r * N4 + (lane ^ (r & 7))] = lpv[u];
+                }
+            }
             cl_publish(fl0 + g, epoch, tid);
         }
         CLB_STAMP(7);
@@ -628,6 +690,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             }
         }
         CLB_STAMP(9);
+        // the records that the FIRST half of the next iteration reads (top of the step .. B3) are requested now: they land
+        // while B6..B11 run from registers and LDS, and the drain of the second publish finds them complete
+        if (t > 0) prefetch_records(ak, t - 1, N, RN, IP);
         // ------------------------------------------------------------ B6: precedence (wave 0 computes the two scalars)
         if (wave == 0) {
             float sw = 0.f, t1 = 0.f;
@@ -882,11 +947,10 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             const int u = u0 + tid;
             float dh = sDHC[u];
             for (int sl = 0; sl < Q.nslH; ++sl) dh += sPart[sl * upk + tid];
-            const f32x4 gg = reinterpret_cast<const f32x4*>(a.rec_gates)[bt * hid + u];
+            const f32x4 gg = pf_gates;
             const float gi = gg[0], gj = gg[1], gf = gg[2], go = gg[3];
-            const float c2 = a.rec_c[bt * hid + u];
-            const float* p_cprev = (t > 0) ? a.rec_c + (bt - 1) * hid : a.hc0 + (size_t)b * 2 * hid + hid;
-            const float cprev = dnc_clip(p_cprev[u], clipv);      // the recorded cell is pre-clip; the carried state was clipped
+            const float c2 = pf_c;
+            const float cprev = dnc_clip(pf_cprev, clipv);        // the recorded cell is pre-clip; the carried state was clipped
             const float tc = tanhf(c2);
             const float h2 = tc * go;
             const float dh2 = (clipv <= 0.f || fabsf(h2) < clipv) ? dh : 0.f;
@@ -997,7 +1061,7 @@ static int dnc_cluster_bwd_pick(int B, int N, int W, int R, int Wn, int hid, int
         if (NR * k != N || NR < 8 || (NR % 8) != 0) continue;
         c = dnc_cluster_cfg(N, W, R, hid, O, k);
         q = dnc_cl_bwd_geo(c);
-        if (c.icg > CT || q.kg4 > CT || c.upk > CT) continue;
+        if (c.IP > CT || c.R * c.N > 2 * CT || q.kg4 > CT || c.upk > CT) continue;
         const DncClBwdLds L = dnc_cl_bwd_lds(c, q);
         const size_t bytes = (size_t)L.total * sizeof(float);
         if (bytes > 160 * 1024) continue;
