@@ -40,7 +40,7 @@ __device__ unsigned long long g_cl_prof[32];
 namespace {
 
 struct DncClFwdLds {
-    int part, M, L, Z, C, I, K, U, NU, KEY, RANK, RW, RWT, WW, P, CW, CR, SC, total;
+    int part, M, L, Z, C, HP, I, K, U, NU, KEY, RANK, RW, RWT, WW, P, CW, CR, SC, total;
 };
 
 // LDS carve-up (offsets in floats) of a shape: constexpr, so the FIX kernel sees immediates
@@ -58,6 +58,7 @@ constexpr __host__ __device__ DncClFwdLds dnc_cl_fwd_lds(const DncClusterCfg& c)
     L.L = o; o += dnc_cluster_align4(c.NR * N);
     L.Z = o; o += dnc_cluster_align4(c.K);
     L.C = o; o += dnc_cluster_align4(c.upk);
+    L.HP = o; o += dnc_cluster_align4(c.upk);             // h_{t-1} of the own units (the deferred output product reads it)
     L.I = o; o += dnc_cluster_align4(c.IP);
     L.K = o; o += dnc_cluster_align4((1 + c.R) * c.W);
     L.U = o; o += dnc_cluster_align4(N);
@@ -111,7 +112,7 @@ typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const int hid = C.hid, K = C.K, IP = C.IP, RWd = R * W, N4 = N >> 2, W4 = W >> 2, WS = W + 4, WS4 = W4 + 1;               \
     const int row0 = g * NR, u0 = min(hid, g * upk), u1 = min(hid, u0 + upk), nU = u1 - u0;                                   \
     float* sPart = smem + L.part; float* sM = smem + L.M; float* sL = smem + L.L;                                             \
-    float* sZ = smem + L.Z; float* sC = smem + L.C; float* sI = smem + L.I; float* sK = smem + L.K;                            \
+    float* sZ = smem + L.Z; float* sC = smem + L.C; float* sHP = smem + L.HP; float* sI = smem + L.I; float* sK = smem + L.K;                            \
     float* sU = smem + L.U; float* sNU = smem + L.NU;                                                                         \
     unsigned long long* sKEY = reinterpret_cast<unsigned long long*>(smem + L.KEY);                                          \
     int* sRank = reinterpret_cast<int*>(smem + L.RANK);                                                                       \
@@ -121,7 +122,7 @@ typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart); f32x4* sM4 = reinterpret_cast<f32x4*>(sM);                              \
     f32x4* sL4 = reinterpret_cast<f32x4*>(sL); const f32x4* sK4 = reinterpret_cast<const f32x4*>(sK);                        \
     (void)upkp; (void)K; (void)IP; (void)RWd; (void)N4; (void)WS; (void)WS4; (void)u1; (void)nU; (void)sPart4; (void)sK4;    \
-    (void)sKEY; (void)sRank; (void)sNU; (void)sCW; (void)sCR; (void)sK; (void)sAbort; (void)sL; (void)sM; (void)sRWT; (void)sI; (void)sC; (void)k
+    (void)sKEY; (void)sRank; (void)sNU; (void)sCW; (void)sCR; (void)sK; (void)sAbort; (void)sL; (void)sM; (void)sRWT; (void)sI; (void)sC; (void)sHP; (void)k
 
 // FIX: the benchmark shape (kDncClusterFixCfg) with every dimension, offset and LDS address a compile-time constant:
 // the short per-row and per-slot loops unroll, their LDS loads are issued in batches instead of one dependent load
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
             const float c2 = gf * sC[tid] + gi * gj;
             const float h2 = tanhf(c2) * go;
             sC[tid] = dnc_clip(c2, clipv);                           // dnc.py:112-113
+            sHP[tid] = sZ[RWd + u0 + tid];                           // h_{t-1}: still needed by the deferred output of step t-1
             sZ[RWd + u0 + tid] = dnc_clip(h2, clipv);
             if (rec) {
                 f32x4 ga = {gi, gj, gf, go};
@@ -260,6 +262,23 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
                 cl_store(slot + upkp + c, v);
             }
             cl_publish(fl0 + g, epoch, tid);
+        }
+        // y_{t-1} = clip([h_{t-1} ; reads_{t-1}] Wy + by) (dnc.py:118-122) does not feed the recurrence: workgroup 0 computes it
+        // HERE, in the shadow of the hand-off (its wave 0 polls, waves 1.. have nothing else to do), not on the step's
+        // critical path.  h_{t-1}: sHP for the own units (already overwritten in sZ), sZ for the others (overwritten after the wait).
+        if (g == 0 && t > 0 && wave >= 1 && wave <= C.O) {
+            const int o = wave - 1;
+            float s = 0.f;
+            for (int kk = lane; kk < C.Ky; kk += 64) {
+                const float zv = (kk < hid) ? ((kk >= u0 && kk < u1) ? sHP[kk - u0] : sZ[RWd + kk]) : sZ[kk - hid];
+                s += zv * a.Wy[(size_t)kk * C.OP + o];
+            }
+            s = wave_sum(s);
+            if (lane == 0) {
+                const float pre = s + a.Wy[(size_t)C.Ky * C.OP + o];
+                a.out[(bt - 1) * C.O + o] = dnc_clip(pre, clipv);
+                if (rec) a.rec_ypre[(bt - 1) * C.O + o] = pre;
+            }
         }
         CL_STAMP(2);
         if (!cl_wait(fl0, epoch, k, a.err, sAbort, t_start, tid)) return;
@@ -619,21 +638,6 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
             a.rec_yin[bt * C.ldy + C.Ky + (tid - RWd)] = (tid == RWd) ? 1.f : 0.f;
         }
         __syncthreads();
-        if (g == 0) {
-            for (int o = wave; o < C.O; o += CW) {            // y = clip([h ; reads] Wy + by)   (dnc.py:118-122)
-                float s = 0.f;
-                for (int kk = lane; kk < C.Ky; kk += 64) {
-                    const float zv = (kk < hid) ? sZ[RWd + kk] : sZ[kk - hid];
-                    s += zv * a.Wy[(size_t)kk * C.OP + o];
-                }
-                s = wave_sum(s);
-                if (lane == 0) {
-                    const float pre = s + a.Wy[(size_t)C.Ky * C.OP + o];
-                    a.out[bt * C.O + o] = dnc_clip(pre, clipv);
-                    if (rec) a.rec_ypre[bt * C.O + o] = pre;
-                }
-            }
-        }
         CL_STAMP(14);
     }
 #ifdef NTK_CL_PROF
@@ -647,6 +651,23 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
         const DncClusterCfg C = FIX ? kDncClusterFixCfg : a.c;
         const DncClFwdLds L = FIX ? kDncClFixFwdLds : a.lds;
         CL_FWD_VIEWS();
+        if (g == 0) {                                            // output of the last step (the loop defers each step's by one)
+            const int wave = tid0 >> 6, lane = tid0 & 63;
+            const size_t bt = (size_t)b * S + (S - 1);
+            for (int o = wave; o < C.O; o += CW) {
+                float s = 0.f;
+                for (int kk = lane; kk < C.Ky; kk += 64) {
+                    const float zv = (kk < hid) ? sZ[RWd + kk] : sZ[kk - hid];
+                    s += zv * a.Wy[(size_t)kk * C.OP + o];
+                }
+                s = wave_sum(s);
+                if (lane == 0) {
+                    const float pre = s + a.Wy[(size_t)C.Ky * C.OP + o];
+                    a.out[bt * C.O + o] = dnc_clip(pre, a.clip);
+                    if (a.rec_z != nullptr) a.rec_ypre[bt * C.O + o] = pre;
+                }
+            }
+        }
         f32x4* gM4 = reinterpret_cast<f32x4*>(a.mem + ((size_t)b * N + row0) * W);
         for (int i = tid0; i < NR * W4; i += CT) { const int n = i / W4, j = i - n * W4; gM4[i] = sM4[(row0 + n) * WS4 + j]; }
         f32x4* gL4 = reinterpret_cast<f32x4*>(a.link + ((size_t)b * N + row0) * N);
@@ -682,7 +703,7 @@ extern "C" int ntk_dnc_cluster_prof(unsigned long long* out16) {
 // the cluster size (0 = none) and configuration of a shape; k_req 0 = the largest k that fits
 static int dnc_cluster_pick(int B, int N, int W, int R, int Wn, int hid, int O, int k_req, DncClusterCfg& c, size_t* lds_bytes) {
     if (Wn != 1 || R < 1 || R > 4 || N < 64 || (N % 64) != 0 || N > CT || W < 4 || (W % 4) != 0 || W > 256 || hid < 4 ||
-        hid > 1024 || O < 1 || O > CW || B < 1)
+        hid > 1024 || O < 1 || O > CW - 1 || B < 1)
         return 0;
     for (int k = 8; k >= 1; k >>= 1) {
         if (k_req > 0 && k != k_req) continue;
