@@ -97,6 +97,18 @@ __device__ __forceinline__ float group_sum_rt(float v, int G) {
     }
 }
 
+// Reciprocal / square root on the hardware transcendental units (v_rcp_f32, v_sqrt_f32: ~1 ulp).  The per-row score and
+// norm terms of the memory passes are computed by every lane of a row's group: with IEEE division (a ~10-instruction
+// Newton sequence each) they were a third of the backward memory passes' instructions.
+__device__ __forceinline__ float cl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float cl_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// Pointwise functions of the controller / interface on the hardware exp / log / rcp units (v_exp_f32, v_log_f32, ~1-2 ulp),
+// as the NTM sequence kernels do (ntm_common.h): the snt.LSTM pointwise step of 25 units sits on the step's critical path.
+__device__ __forceinline__ float cl_sigmoid(float x) { return cl_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float cl_tanh(float x) { return 1.0f - 2.0f * cl_rcp(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float cl_softplus(float x) { return fmaxf(x, 0.f) + __logf(1.0f + __expf(-fabsf(x))); }
+
 // LDS image of the link slice: row r (local), column c -> float index.  float4 groups are XOR-swizzled with the row
 // so that the row-major float4 / scalar accesses of the update and of the backward-read MFMA operand are
 // conflict-free and the column-major scalar reads of the forward-read operand are 4-way at worst.

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                 if (q < NQ) {
                     const int n = grp + 32 * q;
                     const f32x4 m = Mt[q];
-                    const float nm = sqrtf(group_sum<16>(cl_dot4(m, m)) + EPS);
+                    const float nm = cl_sqrt(group_sum<16>(cl_dot4(m, m)) + EPS);
                     nmr[q] = nm;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                             const float dot = group_sum<16>(cl_dot4(kr[i], m));
                             if (gl == 0) {
                                 sG[i * N + n] = sgRW[i * N + n] + t1;
-                                sSIMr[i * N + n] = dot / (sSC[i] * nm + EPS);
+                                sSIMr[i * N + n] = dot * cl_rcp(sSC[i] * nm + EPS);
                             }
                         }
                     }
@@ -468,8 +468,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                             const float dsim = sDSIM[i * N + n];
                             const float D = krn[i] * nm + EPS;
                             const float dot = sSIMr[i * N + n] * D;
-                            const float ddot = dsim / D;
-                            const float dD = -dsim * dot / (D * D);
+                            const float rD = cl_rcp(D);
+                            const float ddot = dsim * rD;
+                            const float dD = -dsim * dot * rD * rD;
                             dnm += dD * krn[i];
                             if (gl == 0) accNk[i] += dD * nm;
                             const float rwn = sRWt[i * N + n];
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                             accK[i] += ddot * m;
                         }
                     }
-                    gq += (dnm / nm) * m;
+                    gq += (dnm * cl_rcp(nm)) * m;
                     gMr[q] = gq;
                 }
                 if (FIX || q == 3) __builtin_amdgcn_sched_barrier(0);
@@ -738,11 +739,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     gMr[q] = gq;                                   // now d(M_{t-1}) (content part added in B10)
                     t1 = group_sum<16>(t1);
                     const float dot = group_sum<16>(cl_dot4(kp, mp));
-                    const float nm = sqrtf(group_sum<16>(cl_dot4(mp, mp)) + EPS);
+                    const float nm = cl_sqrt(group_sum<16>(cl_dot4(mp, mp)) + EPS);
                     nmw[q] = nm;
                     if (gl == 0) {
                         sDWW[n] += t1;
-                        sSIMw[n] = dot / (nkw * nm + EPS);
+                        sSIMw[n] = dot * cl_rcp(nkw * nm + EPS);
                     }
                 }
                 if (FIX || q == 3) __builtin_amdgcn_sched_barrier(0);
@@ -837,10 +838,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     const float dsim = sDCW[n] * bw;
                     const float D = nk * nm + EPS;
                     const float dot = sSIMw[n] * D;
-                    const float ddot = dsim / D;
-                    const float dD = -dsim * dot / (D * D);
+                    const float rD = cl_rcp(D);
+                    const float ddot = dsim * rD;
+                    const float dD = -dsim * dot * rD * rD;
                     if (gl == 0) accNkw += dD * nm;
-                    gMr[q] += ddot * kp + (dD * nk / nm) * mp;
+                    gMr[q] += ddot * kp + (dD * nk * cl_rcp(nm)) * mp;
                     accKw += ddot * mp;
                 }
                 if (FIX || q == 3) __builtin_amdgcn_sched_barrier(0);
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             const float gi = gg[0], gj = gg[1], gf = gg[2], go = gg[3];
             const float c2 = pf_c;
             const float cprev = dnc_clip(pf_cprev, clipv);        // the recorded cell is pre-clip; the carried state was clipped
-            const float tc = tanhf(c2);
+            const float tc = cl_tanh(c2);
             const float h2 = tc * go;
             const float dh2 = (clipv <= 0.f || fabsf(h2) < clipv) ? dh : 0.f;
             const float dcc = (clipv <= 0.f || fabsf(c2) < clipv) ? sgC[tid] : 0.f;

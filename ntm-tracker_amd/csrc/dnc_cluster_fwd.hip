@@ -225,11 +225,11 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
         if (tid < nU) {
             f32x4 gsum = xg;
             for (int ks = 0; ks < ksl; ++ks) gsum += sPart4[ks * upk + tid];
-            const float gi = dnc_sigmoid(gsum[0]), gj = tanhf(gsum[1]);
-            const float gf = dnc_sigmoid(gsum[2] + 1.0f);            // snt.LSTM forget_bias = 1.0
-            const float go = dnc_sigmoid(gsum[3]);
+            const float gi = cl_sigmoid(gsum[0]), gj = cl_tanh(gsum[1]);
+            const float gf = cl_sigmoid(gsum[2] + 1.0f);             // snt.LSTM forget_bias = 1.0
+            const float go = cl_sigmoid(gsum[3]);
             const float c2 = gf * sC[tid] + gi * gj;
-            const float h2 = tanhf(c2) * go;
+            const float h2 = cl_tanh(c2) * go;
             sC[tid] = dnc_clip(c2, clipv);                           // dnc.py:112-113
             sHP[tid] = sZ[RWd + u0 + tid];                           // h_{t-1}: still needed by the deferred output of step t-1
             sZ[RWd + u0 + tid] = dnc_clip(h2, clipv);
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
                 for (int j = j0; j < j1; ++j) { const f32x4 m = mr[j]; nsq += cl_dot4(m, m); dot += cl_dot4(sK4[j], m); }
                 nsq = cl_pair_sum(nsq);
                 dot = cl_pair_sum(dot);
-                if (h == 0) sCW[n] = (dot / (kn * sqrtf(nsq + EPS) + EPS)) * bw;
+                if (h == 0) sCW[n] = (dot * cl_rcp(kn * cl_sqrt(nsq + EPS) + EPS)) * bw;
             }
         }
         // ------------------------------------------------------------ P5a: rank of every slot in the usage order
@@ -460,10 +460,10 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
                 nsq = cl_pair_sum(nsq);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (i < R) dot[i] = cl_pair_sum(dot[i]);
-                const float nm = sqrtf(nsq + EPS);
+                const float nm = cl_sqrt(nsq + EPS);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < R && (i & 1) == h) sCR[i * N + n] = (dot[i] / (krn[i] * nm + EPS)) * br[i];
+                    if (i < R && (i & 1) == h) sCR[i * N + n] = (dot[i] * cl_rcp(krn[i] * nm + EPS)) * br[i];
             }
         }
         CL_STAMP(8);
