@@ -125,3 +125,36 @@ def test_config5_shape_dnc_training_step_properties(cuda):
     full.opt.step()
     loss_2, _ = full.loss_and_grads(*args)
     assert float(loss_2.cpu()) < float(loss_f.cpu())
+
+
+def test_config3_fullsize_dnc_training_step_properties(cuda):
+    """BASELINE config 3 at full size (DNC 256x64, 4 read heads; 32 sequences x 20 frames -> 1300 strictly sequential
+    steps, every CU of the chip in an 8-workgroup cluster per sequence): the whole training step (recorded forward,
+    loss, BPTT, weight-gradient GEMMs) is finite, bitwise reproducible run to run (fixed-order reductions and
+    hand-offs: no float atomics on the cluster path), no hand-off times out, and duplicating a half batch doubles the
+    un-normalised loss and the gradient (the property the data-parallel SUM all-reduce relies on)."""
+    from ntmtrack import tracker
+    B, T = 32, 20
+    g = torch.Generator().manual_seed(12)
+    fmap_h = torch.relu(torch.randn((B // 2 * T, 28, 28, 512), generator=g)).to(cuda)
+    gts_h = torch.rand((B // 2, 64), generator=g).to(cuda)
+    offs_h = (torch.rand((B // 2, T, 2), generator=g) - 0.5).to(cuda)
+    kw = dict(vgg_weights=None, mem_size=256, mem_dim=64, device=cuda, seed=6)
+    half = tracker.DNCOffsetTracker(B // 2, T, **kw)
+    loss_h, _ = half.loss_and_grads(fmap_h, gts_h, offs_h)
+    half.core.check_cluster()
+    assert half.core.last_cluster_k == 8 and half.core.last_cluster_bwd_k == 8
+    args = (torch.cat([fmap_h, fmap_h]), torch.cat([gts_h, gts_h]), torch.cat([offs_h, offs_h]))
+    grads = []
+    for _ in range(2):
+        full = tracker.DNCOffsetTracker(B, T, **kw)
+        loss_f, _ = full.loss_and_grads(*args)
+        full.core.check_cluster()
+        assert full.core.last_cluster_k == 8 and full.core.last_cluster_bwd_k == 8
+        grads.append(full.core.params.grad.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(grads[0], grads[1]), "the DNC training step is not bitwise reproducible"
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+    np.testing.assert_allclose(float(loss_f.cpu()), 2 * float(loss_h.cpu()), rtol=1e-5)
+    gh, gf = half.core.params.grad, grads[0]
+    assert float((gf - 2 * gh).abs().max() / gf.abs().max()) < 1e-4
