@@ -136,38 +136,77 @@ def cpu_baseline(ws, n_vgg_frames=8, T=20):
     return out
 
 
-def memory_step_probe(trk, model, gts0, B, T):
-    """The memory cell's recurrent forward pass alone (outside the timed region): algorithmic state bytes per
-    sequence-step (state read once + written once per step) x B x S / time, against the 8 TB/s HBM peak.
-    The cell keeps its state on-chip (NTM: LDS; DNC: L2) and the S steps of a sequence are strictly dependent, so this
-    pass is bound by the per-step dependency chain, not by HBM: the fraction is reported as SURVEY defines it and the
-    per-step latency is the figure that matters."""
-    S = T * 65
-    fmap = trk._slots[0]["buf"]
+# HBM-side bytes of the DNC cluster kernels at configs[2] (B 32, S 1300): profiles/r02_dnc_cluster_hbm_traffic_pmc.csv
+DNC_FWD_TRAFFIC_BYTES_B32_S1300 = 4.56e9        # inference-mode forward (2 x FETCH_SIZE + WRITE_SIZE)
+DNC_BWD_TRAFFIC_BYTES_B32_S1300 = 2.123e10
+NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.95e9 + 0.16e9   # profiles/r01_ntm_seq_hbm_traffic_pmc.csv
+
+
+def _median_ms(fn, n=3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
     times = []
-    for _ in range(3):
+    for _ in range(n):
         e0.record()
-        trk.forward_features(fmap, gts0)
+        fn()
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
-    ms = float(np.median(times))
+    return float(np.median(times))
+
+
+def memory_step_probe(trk, model, gts0, offs, B, T):
+    """The memory cell's recurrent passes alone (outside the timed region): algorithmic state bytes per sequence-step
+    (state read once + written once per step) x B x S / time, against the 8 TB/s HBM peak, for the forward
+    pass and for BPTT (which touches the same state plus its gradient: priced with the same per-step bytes).
+    The cells keep their state on-chip (NTM: LDS of one CU per sequence; DNC: LDS / registers of a cluster of 8 CUs per
+    sequence) and the S steps of a sequence are strictly dependent, so these passes are bound by the per-step
+    dependency chain (and, for the DNC, by the two hand-offs per step), not by HBM: the fraction is reported as SURVEY
+    defines it, next to the HBM-side bytes the kernels really move (PMC) and the per-step latency."""
+    from ntmtrack import tracker as T_
+    S = T * 65
+    fmap = trk._slots[0]["buf"]
+    torch.cuda.synchronize()
+    ms = _median_ms(lambda: trk.forward_features(fmap, gts0))
     if model == "ntm":
         d = trk.cell.dims
         per_step = 2 * d.N * d.Md * 4 + 2 * d.H * d.N * 4 + 2 * d.R * d.Md * 4 + d.P * 4
+        X, st0, logits, rec = trk.forward_features(fmap, gts0, record=True)
+        _loss, _pred, dlogits = T_.offset_loss(logits, offs, T)
+        ms_b = _median_ms(lambda: trk.cell.backward_sequence(X, st0, rec, dlogits))
+        kern, kern_b = "ntm_seq_fwd_kernel", "ntm_seq_bwd_kernel (+ 3 weight-gradient GEMMs)"
+        traffic = NTM_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)
+        traffic_b = NTM_BWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)
+        note = "serialise + input projection + persistent sequence kernel, one workgroup per sequence; state is LDS resident"
+        tnote = "PMC, profiles/r01_ntm_seq_hbm_traffic_pmc.csv: input projection read + per-step BPTT records; the memory state itself never leaves LDS"
     else:
         c = trk.core
         per_step = 2 * c.N * c.W * 4 + 2 * c.Wn * c.N * c.N * 4 + 2 * (c.R + c.Wn) * c.N * 4 + 2 * c.Wn * c.N * 4 + 2 * c.N * 4
-    gbps = per_step * B * S / (ms * 1e-3) / 1e9
-    return {"kernel": "ntm_seq_fwd_kernel" if model == "ntm" else "dnc_seq_fwd_kernel", "bound": "hbm (nominal); dependency-chain latency (actual)",
-            "algorithmic_bytes_per_sequence_step": per_step, "sequences": B, "steps": S,
-            "forward_ms": round(ms, 3), "us_per_step": round(ms * 1e3 / S, 3),
-            "achieved": round(gbps, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 5),
-            "traffic": (NTM_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)) if model == "ntm" else None,
-            "traffic_note": "HBM-side bytes of the training-mode forward kernel (PMC, profiles/r01_ntm_seq_hbm_traffic_pmc.csv): input projection read + per-step BPTT records written; the memory state itself never leaves LDS",
-            "note": "serialise + input projection + persistent sequence kernel, one workgroup per sequence; state is LDS/L2 resident"}
+        logits, _st = trk.forward_features(fmap, gts0, record=True)
+        _loss, _pred, dlogits = T_.offset_loss(logits, offs, T)
+        ms_b = _median_ms(lambda: c.backward_sequence(trk._X, dlogits))
+        c.check_cluster()
+        k = getattr(c, "last_cluster_k", 1)
+        kern = "dnc_cluster_fwd_kernel (k = %d workgroups per sequence)" % k if k > 1 else "dnc_seq_fwd_kernel"
+        kern_b = ("dnc_cluster_bwd_kernel (k = %d)" % getattr(c, "last_cluster_bwd_k", 1) if getattr(c, "last_cluster_bwd_k", 1) > 1
+                  else "dnc_seq_bwd_kernel") + " (+ 4 weight-gradient GEMMs)"
+        is_c3 = (c.N, c.W, c.R) == (256, 64, 4) and k > 1
+        traffic = DNC_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else None
+        traffic_b = DNC_BWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else None
+        note = ("serialise + input projection + persistent cluster kernel: link rows and memory LDS resident, two mailbox hand-offs per step"
+                if k > 1 else "serialise + input projection + persistent sequence kernel, one workgroup per sequence; link and memory L2 resident")
+        tnote = "PMC, profiles/r02_dnc_cluster_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE)"
+
+    def entry(kernel, t_ms, tr):
+        gbps = per_step * B * S / (t_ms * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": "hbm (nominal); dependency-chain latency (actual)",
+                "algorithmic_bytes_per_sequence_step": per_step, "sequences": B, "steps": S,
+                "ms": round(t_ms, 3), "us_per_step": round(t_ms * 1e3 / S, 3),
+                "achieved": round(gbps, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 5),
+                "traffic": tr, "traffic_note": tnote}
+    fwd = entry(kern, ms, traffic)
+    fwd["forward_ms"] = fwd["ms"]
+    fwd["note"] = note
+    return fwd, entry(kern_b, ms_b, traffic_b)
 
 
 def main():
@@ -341,7 +380,7 @@ def main():
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},
         }
-        out["memory_step"] = memory_step_probe(trk, args.model, gts0, B, T)
+        out["memory_step"], out["memory_step_bptt"] = memory_step_probe(trk, args.model, gts0, offs, B, T)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ws)
         print(json.dumps(out), flush=True)

@@ -236,8 +236,11 @@ class NTMCell(object):
             input_dim = sd["lstm/cell_0/weights"].shape[0] - self.read_head_size * self.mem_dim - self.controller_hidden_size
         self._build(int(input_dim), sd)
 
-    def state_dict(self):
-        return self.params.to_tf()
+    def state_dict(self, grad=False):
+        return self.params.to_tf(grad)
+
+    #: leading dimension of the serialised input rows the cell consumes (features zero padded to a multiple of 4)
+    input_ldx = property(lambda self: self.dims.ldx)
 
     # ---- state helpers
     def zero_state(self, batch_size, initializer=None):
@@ -392,13 +395,43 @@ class NTMCell(object):
     step = __call__
 
 
+class _StackedFlat(object):
+    """One flat fp32 buffer (+ same-shaped gradient) for a deep controller: [packed top cell | lower layer matrices].
+    The top cell's PackedParams is re-pointed at its slice, so the optimiser and the all-reduce stay flat passes."""
+
+    def __init__(self, top_params, lower_shapes, device):
+        n = top_params.numel
+        self.lower_off = []
+        for shp in lower_shapes:
+            n = (n + 3) // 4 * 4
+            self.lower_off.append((n, shp))
+            n += shp[0] * shp[1]
+        self.numel = (n + 3) // 4 * 4
+        self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.flat[:top_params.numel].copy_(top_params.flat)
+        top_params.flat = self.flat[:top_params.numel]
+        top_params.grad = self.grad[:top_params.numel]
+        self.top = top_params
+
+    def lower(self, k, grad=False):
+        o, shp = self.lower_off[k]
+        return (self.grad if grad else self.flat)[o:o + shp[0] * shp[1]].view(shp)
+
+    def view(self, name, grad=False):
+        return self.top.view(name, grad)
+
+
 class StackedNTMCell(NTMCell):
     """NTMCell with a MultiRNNCell controller of L > 1 BasicLSTMCell layers (ntm_cell.py:45-50, :101-105): layer 0 reads
     concat(x, read_prev), layer k reads h_{k-1}, the top layer's h drives the heads.  Layers 0 .. L-2 run as separate
-    LSTM steps (ntk_gemm_nt_f32 + ntk_lstm_step_fwd); the top layer, the addressing and the memory update run in the
-    fused cell kernel (whose read_prev rows of the recurrent matrix are zero here, because read_prev enters at
-    layer 0).  Forward only: step() / run_sequence(); training of deep controllers is not on the HIP path.
-    controller_state layout = [c_0, h_0, c_1, h_1, ...] (state_is_tuple=False, MultiRNNCell concatenation)."""
+    LSTM steps (ntk_gemm_nt_f32 + ntk_lstm_step_fwd/bwd); the top layer, the addressing and the memory update run in
+    the fused cell kernel one step at a time (ntk_ntm_step_fwd/bwd; its read_prev rows of the recurrent matrix are
+    zero here, because read_prev enters at layer 0).  Forward, BPTT (tf.gradients through every layer, direct_offset_
+    output.py:611-621) and training are step-wise launches from Python: functional parity for the reference's deep
+    constructor default, not a tuned path (every reference script runs one layer).
+    controller_state layout = [c_0, h_0, c_1, h_1, ...] (state_is_tuple=False, MultiRNNCell concatenation).
+    Lower layer k is stored as WT_k [4*hid][ld_k]: columns [input | h_prev | bias (the matching input column is 1)]."""
 
     def __init__(self, output_dim, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=100,
                  controller_num_layers=10, write_head_size=3, read_head_size=3, write_first=False,
@@ -411,12 +444,21 @@ class StackedNTMCell(NTMCell):
         self.top = NTMCell(output_dim, mem_size, mem_dim, shift_range, controller_hidden_size, 1, write_head_size,
                            read_head_size, write_first, input_dim=None, device=device, init_scale=init_scale, seed=seed)
         self.D = None
+        self.params = None
         self.lower = []
         if input_dim is not None:
             self._build(int(input_dim))
 
     dims = property(lambda self: self.top.dims)
-    params = property(lambda self: self.top.params)
+    input_ldx = property(lambda self: (self.D + 3) // 4 * 4)
+
+    def _lower_shapes(self):
+        hid, RM = self.controller_hidden_size, self.read_head_size * self.mem_dim
+        shapes, in_dim = [], self.D + RM
+        for _k in range(self.L - 1):
+            shapes.append((4 * hid, (in_dim + hid + 1 + 3) // 4 * 4))
+            in_dim = hid
+        return shapes
 
     def _build(self, input_dim, sd=None):
         hid, RM, L = self.controller_hidden_size, self.read_head_size * self.mem_dim, self.L
@@ -435,32 +477,49 @@ class StackedNTMCell(NTMCell):
                 sd["lstm/cell_%d/biases" % k] = torch.zeros(4 * hid)
                 in_dim = hid
         t = lambda v: torch.as_tensor(v, dtype=torch.float32)
-        self.lower = []
-        in_dim = self.D + RM
-        for k in range(L - 1):
-            W, b = t(sd["lstm/cell_%d/weights" % k]), t(sd["lstm/cell_%d/biases" % k])
-            assert tuple(W.shape) == (in_dim + hid, 4 * hid), W.shape
-            ld = (in_dim + hid + 3) // 4 * 4
-            WT = torch.zeros((4 * hid, ld))
-            WT[:, :in_dim + hid] = W.t()
-            self.lower.append((WT.to(self.device), b.to(self.device).contiguous(), in_dim, ld))
-            in_dim = hid
         Wt, bt = t(sd["lstm/cell_%d/weights" % (L - 1)]), t(sd["lstm/cell_%d/biases" % (L - 1)])
         assert tuple(Wt.shape) == (2 * hid, 4 * hid), Wt.shape
         top_sd = {k: sd[k] for k in ("addressing/weights", "addressing/biases", "output/weights", "output/biases",
                                       "init_state/M", "init_state/w", "init_state/read")}
         top_sd["lstm/cell_0/weights"] = torch.cat([Wt[:hid], torch.zeros((RM, 4 * hid)), Wt[hid:]], dim=0)
         top_sd["lstm/cell_0/biases"] = bt
-        self.top._build(hid, top_sd)
-        self._sd = {k: t(v).clone() for k, v in sd.items()}
+        keep = self.params is not None and self.top.params is not None and self.params.lower_off and \
+            [shp for _o, shp in self.params.lower_off] == self._lower_shapes()
+        self.top._build(hid, top_sd)           # same layout -> loads into the existing (shared) flat buffer
+        if not keep:
+            self.params = _StackedFlat(self.top.params, self._lower_shapes(), self.device)
+        self.lower = []
+        in_dim = self.D + RM
+        for k in range(L - 1):
+            W, b = t(sd["lstm/cell_%d/weights" % k]), t(sd["lstm/cell_%d/biases" % k])
+            assert tuple(W.shape) == (in_dim + hid, 4 * hid), W.shape
+            WT = self.params.lower(k)
+            ld = WT.shape[1]
+            host = torch.zeros((4 * hid, ld))
+            host[:, :in_dim + hid] = W.t()
+            host[:, in_dim + hid] = b
+            WT.copy_(host.to(self.device))
+            self.lower.append((WT, in_dim, ld))
+            in_dim = hid
 
     def load_state_dict(self, sd, input_dim=None):
         if input_dim is None:
             input_dim = sd["lstm/cell_0/weights"].shape[0] - self.read_head_size * self.mem_dim - self.controller_hidden_size
         self._build(int(input_dim), sd)
 
-    def state_dict(self):
-        return {k: v.clone() for k, v in self._sd.items()}
+    def state_dict(self, grad=False):
+        """Variables under the reference's names (lstm/cell_k/{weights,biases}, ...); grad=True: their gradients."""
+        hid, RM, L = self.controller_hidden_size, self.read_head_size * self.mem_dim, self.L
+        top = self.top.params.to_tf(grad)
+        out = {k: v for k, v in top.items() if not k.startswith("lstm/")}
+        Wt = top["lstm/cell_0/weights"]
+        out["lstm/cell_%d/weights" % (L - 1)] = torch.cat([Wt[:hid], Wt[hid + RM:]], dim=0).contiguous()
+        out["lstm/cell_%d/biases" % (L - 1)] = top["lstm/cell_0/biases"]
+        for k, (_WT, in_dim, _ld) in enumerate(self.lower):
+            WT = self.params.lower(k, grad).cpu()
+            out["lstm/cell_%d/weights" % k] = WT[:, :in_dim + hid].t().contiguous()
+            out["lstm/cell_%d/biases" % k] = WT[:, in_dim + hid].contiguous()
+        return out
 
     def state_placeholder(self, batch_size):
         st = self.top.state_placeholder(batch_size)
@@ -472,54 +531,147 @@ class StackedNTMCell(NTMCell):
         st["controller_state"] = torch.zeros((batch_size, 2 * self.controller_hidden_size * self.L), device=self.device)
         return st
 
+    # ---- one step (optionally recorded for BPTT)
+    def _step(self, x, state, record):
+        hid, L = self.controller_hidden_size, self.L
+        B = x.shape[0]
+        lib, stream = _lib.lib(), _lib.stream()
+        cs = state["controller_state"].contiguous()
+        inp = torch.cat([x.to(self.device, torch.float32)[:, :self.D], state["read"].reshape(B, -1)], dim=1)
+        new_cs, lrec = [], []
+        for k, (WT, in_dim, ld) in enumerate(self.lower):
+            buf = torch.zeros((B, ld), device=self.device)
+            buf[:, :in_dim] = inp
+            buf[:, in_dim:in_dim + hid] = cs[:, 2 * hid * k + hid:2 * hid * (k + 1)]
+            buf[:, in_dim + hid] = 1.0                                    # bias column
+            pre = gemm_nt(buf, WT)
+            c_prev = cs[:, 2 * hid * k:2 * hid * k + hid].contiguous()
+            c, h = torch.empty((B, hid), device=self.device), torch.empty((B, hid), device=self.device)
+            act = torch.empty((B, 4 * hid), device=self.device) if record else None
+            _lib.check(lib.ntk_lstm_step_fwd(_P(pre), _P(c_prev), 0.0, _P(c), _P(h), _np(act), B, hid, stream), "ntk_lstm_step_fwd")
+            new_cs += [c, h]
+            if record:
+                lrec.append({"buf": buf, "act": act, "c_prev": c_prev, "c": c})
+            inp = h
+        top_state = {"M": state["M"], "w": state["w"], "read": state["read"],
+                     "controller_state": cs[:, 2 * hid * (L - 1):].contiguous()}
+        Xt = self.top._pad_inputs(inp.unsqueeze(1))
+        logits, outputs, new, rec = self.top.run_sequence(Xt, top_state, record=True)
+        full_cs = torch.cat(new_cs + [new["controller_state"]], dim=1)
+        new_state = {"M": new["M"], "w": new["w"], "read": new["read"], "controller_state": full_cs}
+        srec = {"lower": lrec, "top": rec, "Xtop": Xt, "top_state": top_state} if record else None
+        return outputs[:, 0], logits[:, 0], new_state, rec, srec
+
     def __call__(self, inputs, prev_state, M_prev=None, w_prev=None, read_prev=None, controller_state=None, scope=None):
         if self.D is None:
             self._build(inputs.shape[1])
         if prev_state is not None:
             M_prev, w_prev = prev_state["M"], prev_state["w"]
             read_prev, controller_state = prev_state["read"], prev_state["controller_state"]
-        hid, L = self.controller_hidden_size, self.L
-        B = inputs.shape[0]
-        lib, stream = _lib.lib(), _lib.stream()
-        cs = controller_state.contiguous()
-        inp = torch.cat([inputs.to(self.device, torch.float32), read_prev.reshape(B, -1)], dim=1)
-        new_cs = []
-        for k, (WT, bias, in_dim, ld) in enumerate(self.lower):
-            buf = torch.zeros((B, ld), device=self.device)
-            buf[:, :in_dim] = inp
-            buf[:, in_dim:in_dim + hid] = cs[:, 2 * hid * k + hid:2 * hid * (k + 1)]
-            pre = gemm_nt(buf, WT, bias)
-            c_prev = cs[:, 2 * hid * k:2 * hid * k + hid].contiguous()
-            c, h = torch.empty((B, hid), device=self.device), torch.empty((B, hid), device=self.device)
-            _lib.check(lib.ntk_lstm_step_fwd(_P(pre), _P(c_prev), 0.0, _P(c), _P(h), None, B, hid, stream), "ntk_lstm_step_fwd")
-            new_cs += [c, h]
-            inp = h
-        top_state = {"M": M_prev, "w": w_prev, "read": read_prev,
-                     "controller_state": cs[:, 2 * hid * (L - 1):].contiguous()}
-        out, logit, st, debug, M, w, read, top_cs = self.top(inp, top_state)
-        full_cs = torch.cat(new_cs + [top_cs], dim=1)
-        st = dict(st)
-        st["controller_state"] = full_cs
-        return (out, logit, st, debug, M, w, read, full_cs)
+        st = {"M": M_prev, "w": w_prev, "read": read_prev, "controller_state": controller_state}
+        out, logit, new, rec, _ = self._step(inputs, st, False)
+        d = self.dims
+        B, H, Md, R = inputs.shape[0], d.H, d.Md, d.R
+        u, w = rec["u"][:, 0], rec["w"][:, 0]
+        debug = {"k": u[:, d.oK:d.oB].reshape(B, H, Md), "bega": u[:, d.oB:d.oG].unsqueeze(-1),
+                 "g": u[:, d.oG:d.oS].unsqueeze(-1), "gamma": u[:, d.oY:d.oE].unsqueeze(-1),
+                 "erase": u[:, d.oE:d.oA].reshape(B, d.Wh, Md), "add": u[:, d.oA:d.P].reshape(B, d.Wh, Md),
+                 "w_content_focused": rec["wc"][:, 0], "w_conv": rec["wv"][:, 0], "w": w, "w_read": w[:, :R],
+                 "w_write": w[:, R:], "M": new["M"], "M_prev": M_prev}
+        return (out, logit, new, debug, new["M"], new["w"], new["read"], new["controller_state"])
 
     step = __call__
 
     def run_sequence(self, X, state, record=False, want_outputs=True, after_projection=None):
-        """Python loop over step() (the LoopNTMTracker fallback for deep controllers)."""
-        if record:
-            raise _lib.NtkError("StackedNTMCell: BPTT records are not available for controller_num_layers > 1")
+        """Python loop over steps (the LoopNTMTracker fallback for deep controllers).  record=True keeps what
+        backward_sequence needs."""
         B, S, _ = X.shape
-        logits, outs = [], []
+        logits, outs, steps = [], [], []
         for t in range(S):
-            r = self(X[:, t, :self.D], state)
-            outs.append(r[0]); logits.append(r[1]); state = r[2]
-        return torch.stack(logits, 1), (torch.stack(outs, 1) if want_outputs else None), state, {}
+            o, l, state, _rec, srec = self._step(X[:, t], state, record)
+            outs.append(o); logits.append(l)
+            if record:
+                steps.append(srec)
+        return torch.stack(logits, 1), (torch.stack(outs, 1) if want_outputs else None), state, ({"steps": steps} if record else {})
 
     def _pad_inputs(self, inputs):
         return inputs
 
-    def backward_sequence(self, *a, **k):
-        raise _lib.NtkError("training of controller_num_layers > 1 is not implemented on the HIP path")
+    def backward_sequence(self, X, state0, rec, dlogits, dfinal=None, workspace=None):
+        """BPTT through a recorded sequence of the deep controller: fills ``self.params.grad`` (top cell in kernel
+        layout, lower layers as WT_k) and returns the gradient w.r.t. the initial state tensors."""
+        steps = rec["steps"]
+        S, B = len(steps), X.shape[0]
+        hid, L, dev = self.controller_hidden_size, self.L, self.device
+        d, lib, stream = self.dims, _lib.lib(), _lib.stream()
+        TP = self.top.params
+        ldkT, ldhT = (d.K + 3) // 4 * 4, (d.hid + 3) // 4 * 4
+        WrT = torch.empty((4 * hid, ldkT), device=dev)
+        WaT = torch.empty((d.PP, ldhT), device=dev)
+        _lib.check(lib.ntk_transpose_pad(_P(TP.view("Wr")), 4 * hid, _P(WrT), ldkT, d.K, 4 * hid, stream), "ntk_transpose_pad")
+        _lib.check(lib.ntk_transpose_pad(_P(TP.view("Wa")), d.PP, _P(WaT), ldhT, hid, d.PP, stream), "ntk_transpose_pad")
+        Wx_top = TP.view("WxT").t().contiguous()                       # [ldx_top][4*hid]: d(top input) = dgates @ WxT
+        W_low = [WT.t().contiguous() for WT, _i, _l in self.lower]      # [ld_k][4*hid]
+        z = lambda *s_: torch.zeros(s_, device=dev)
+        df = dfinal or {}
+        dM = df.get("M", z(B, d.N, d.Md)).contiguous()
+        dw = df.get("w", z(B, d.H, d.N)).contiguous()
+        dread = df.get("read", z(B, d.R, d.Md)).contiguous()
+        dcs_full = df.get("controller_state", z(B, 2 * hid * L))
+        dcs_top = dcs_full[:, 2 * hid * (L - 1):].contiguous()
+        dc_low = [dcs_full[:, 2 * hid * k:2 * hid * k + hid].contiguous() for k in range(L - 1)]
+        dh_low = [dcs_full[:, 2 * hid * k + hid:2 * hid * (k + 1)].contiguous() for k in range(L - 1)]
+        dgates_all = torch.empty((B, S, 4 * hid), device=dev)
+        du_all = torch.empty((B, S, d.PP), device=dev)
+        dpre_all = [torch.empty((B, S, 4 * hid), device=dev) for _ in range(L - 1)]
+        dl = dlogits.contiguous()
+        for t in range(S - 1, -1, -1):
+            st, r, ts = steps[t], steps[t]["top"], steps[t]["top_state"]
+            dgates, du = torch.empty((B, 4 * hid), device=dev), torch.empty((B, d.PP), device=dev)
+            g0 = self.top.state_placeholder(B)
+            dlt = dl[:, t].contiguous()
+            _lib.check(lib.ntk_ntm_step_bwd(
+                B, d.N, d.Md, d.R, d.Wh, d.hid, d.shift_range, d.O, 1 if self.write_first else 0,
+                _P(WrT), ldkT, _P(WaT), ldhT, _P(ts["M"].contiguous()), _P(ts["w"].contiguous()), _P(ts["controller_state"]),
+                _P(r["gates"]), _P(r["c"]), _P(r["u"]), _P(r["wc"]), _P(r["wv"]), _P(r["w"]), _P(r["M"]), _P(dlt),
+                _P(dM), _P(dw), _P(dread), _P(dcs_top),
+                _P(dgates), _P(du), _P(g0["M"]), _P(g0["w"]), _P(g0["read"]), _P(g0["controller_state"]), stream),
+                "ntk_ntm_step_bwd")
+            dgates_all[:, t], du_all[:, t] = dgates, du
+            dM, dw, dcs_top = g0["M"], g0["w"], g0["controller_state"]
+            dread_prev = g0["read"]                                        # zero-weight path of the fused cell (kept for exactness)
+            dx = gemm_nt(dgates, Wx_top)[:, :hid]                          # gradient of the top layer's input h_{L-2}(t)
+            for k in range(L - 2, -1, -1):
+                WT, in_dim, ld = self.lower[k]
+                lr = st["lower"][k]
+                dh = (dx + dh_low[k]).contiguous()
+                dpre, dc_prev = torch.empty((B, 4 * hid), device=dev), torch.empty((B, hid), device=dev)
+                _lib.check(lib.ntk_lstm_step_bwd(_P(lr["act"]), _P(lr["c_prev"]), _P(lr["c"]), _P(dh), _P(dc_low[k]), _P(dpre), _P(dc_prev),
+                                                 B, hid, stream), "ntk_lstm_step_bwd")
+                dpre_all[k][:, t] = dpre
+                dbuf = gemm_nt(dpre, W_low[k])                              # [B, ld_k]
+                dc_low[k] = dc_prev
+                dh_low[k] = dbuf[:, in_dim:in_dim + hid].contiguous()
+                dx = dbuf[:, :in_dim]
+            dread = (dread_prev.reshape(B, -1) + dx[:, self.D:]).reshape(B, d.R, d.Md).contiguous()   # layer 0 reads read_{t-1}
+        BS = B * S
+        # weight gradients: k-major contractions over all recorded rows (bias = the ones column of the recorded inputs)
+        Xtop = torch.stack([st["Xtop"][:, 0] for st in steps], 1).contiguous()
+        cat = lambda key: torch.stack([st["top"][key][:, 0] for st in steps], 1).contiguous()
+        gemm_tn(dgates_all.view(BS, 4 * hid), Xtop.view(BS, d.ldx), TP.view("WxT", grad=True), workspace=workspace)
+        gemm_tn(cat("z").view(BS, d.ldz), dgates_all.view(BS, 4 * hid), TP.view("Wr", grad=True), workspace=workspace)
+        gemm_tn(cat("h").view(BS, d.ldh), du_all.view(BS, d.PP), TP.view("Wa", grad=True), workspace=workspace)
+        # the read_prev rows of the fused cell's recurrent matrix are structural zeros here (read_prev enters at layer 0)
+        TP.view("Wr", grad=True)[:d.RM].zero_()
+        for k, (WT, in_dim, ld) in enumerate(self.lower):
+            bufs = torch.stack([st["lower"][k]["buf"] for st in steps], 1).contiguous()
+            gemm_tn(dpre_all[k].view(BS, 4 * hid), bufs.view(BS, ld), self.params.lower(k, grad=True), workspace=workspace)
+        g0 = {"M": dM, "w": dw, "read": dread,
+              "controller_state": torch.cat([t_ for k in range(L - 1) for t_ in (dc_low[k], dh_low[k])] + [dcs_top], dim=1)}
+        return g0
+
+    def init_state_backward(self, g0, batch_size):
+        self.top.init_state_backward(g0, batch_size)
 
 
 class LoopNTMTracker(object):

@@ -216,7 +216,7 @@ class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         return self.vgg(frames)
 
     def serialize(self, fmap, gts0):
-        return gather_serialize(fmap, gts0, self.B, self.T, self.cell.dims.ldx)
+        return gather_serialize(fmap, gts0, self.B, self.T, self.cell.input_ldx)
 
     def forward_features(self, fmap, gts0, record=False):
         X = self.serialize(fmap, gts0)

@@ -10,13 +10,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_emits_contract_json(cuda, capsys, monkeypatch):
+@pytest.mark.parametrize("model", ["ntm", "dnc"])
+def test_bench_emits_contract_json(cuda, capsys, monkeypatch, model):
     # in-process (this process already owns the GPU: no exec of a second program from here)
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
-                                      "--seq-len", "2", "--no-cpu-baseline"])
+                                      "--seq-len", "2", "--no-cpu-baseline", "--model", model])
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     bench.main()
@@ -24,7 +25,7 @@ def test_bench_emits_contract_json(cuda, capsys, monkeypatch):
     assert len(lines) == 1
     out = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "memory_step"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "memory_step", "memory_step_bptt"):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
     assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["data"] == "synthetic" and out["dtype"] == "f32"
@@ -36,5 +37,11 @@ def test_bench_emits_contract_json(cuda, capsys, monkeypatch):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.0 < r["frac"] <= 1.0, "roofline.frac is executed MFMA flops / peak: a utilisation"
     assert r["algorithmic_tflops"] >= r["achieved"]
+    for ms in (out["memory_step"], out["memory_step_bptt"]):
+        for key in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "us_per_step"):
+            assert key in ms, key
+        assert ms["unit"] == "GB/s" and 0.0 < ms["frac"] <= 1.0
+    if model == "dnc":
+        assert "cluster" in out["memory_step"]["kernel"] and "cluster" in out["memory_step_bptt"]["kernel"]
     # frames/s = frames per step / seconds per step
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2

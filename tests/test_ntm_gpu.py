@@ -115,12 +115,6 @@ def test_zero_state_matches_oracle(cuda):
 def test_unsupported_configs_fail_loudly(cuda):
     from ntmtrack.ntm import NTMCell
     from ntmtrack._lib import NtkError
-    deep = NTMCell(2, controller_num_layers=3, mem_size=64, mem_dim=8, controller_hidden_size=16, write_head_size=1,
-                   read_head_size=1, input_dim=6, device=cuda)
-    with pytest.raises(NtkError):                                   # deep controllers: forward only
-        deep.run_sequence(torch.zeros((1, 2, 6), device=cuda), deep.zero_state(1), record=True)
-    with pytest.raises(NtkError):
-        deep.backward_sequence()
     cell = NTMCell(2, mem_size=100, mem_dim=20, controller_hidden_size=64, controller_num_layers=1,
                    write_head_size=1, read_head_size=1, input_dim=8, device=cuda)
     with pytest.raises(NtkError):                                   # mem_size must be a multiple of 64

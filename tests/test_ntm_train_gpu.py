@@ -229,3 +229,54 @@ def test_full_length_bptt_gradients_match_autograd_oracle(cuda):
     for k, v in worst.items():
         print("  %-24s %.3e" % (k, v))
     assert max(worst.values()) < 5e-5, worst          # measured 2e-8 .. 4e-6 (GPUTEST r2)
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+def test_deep_controller_bptt_matches_autograd_oracle(cuda, layers):
+    """controller_num_layers > 1 (MultiRNNCell of BasicLSTMCells, ntm_cell.py:45-50; the constructor default is 10):
+    loss and the gradient of EVERY variable, lower LSTM layers included, through the tracking head over T = 2 frames
+    (130 steps) against the float64 torch-autograd restatement; then one clipped RMSProp step moves all of them."""
+    from ntmtrack import tracker
+    from ntmtrack.ntm import StackedNTMCell
+    B, T = 2, 2
+    kw = dict(mem_size=64, mem_dim=8, shift_range=1, controller_hidden_size=32, controller_num_layers=layers,
+              write_head_size=1, read_head_size=2)
+    cfg = O.NTMConfig(514, 2, **kw)
+    rng = np.random.default_rng(50 + layers)
+    params = O.init_params(cfg, rng, scale=0.15)
+    for k in params:
+        if k.endswith("biases"):
+            params[k] = rng.uniform(-0.15, 0.15, size=params[k].shape).astype(np.float32)
+    feats = np.maximum(rng.standard_normal((B, T, 64, 512)), 0).astype(np.float32)
+    gts = rng.uniform(0, 1, size=(B, T, 64)).astype(np.float32)
+    x = O.serialize_inputs(feats, gts)
+    offs = rng.uniform(-0.5, 0.5, size=(B, T, 2)).astype(np.float32)
+    loss_ref, grads_ref, logits_ref, _ = OT.loss_and_grads(cfg, params, x, offs)
+    assert any(k.startswith("lstm/cell_%d/" % (layers - 1)) for k in grads_ref)
+
+    trk = tracker.NTMOffsetTracker(B, T, vgg_weights=None, mem_size=64, mem_dim=8, hidden_size=32, num_layers=layers,
+                                   read_head_size=2, write_head_size=1, device=cuda, learning_rate=1e-2)
+    assert isinstance(trk.cell, StackedNTMCell)
+    trk.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    assert trk.opt.p is trk.cell.params
+    fmap = np.zeros((B * T, 28, 28, 512), np.float32)
+    for i, (y, xx) in enumerate(O.CONV43_POINTS):
+        fmap[:, y, xx, :] = feats.reshape(B * T, 64, 512)[:, i]
+    loss, _ = trk.loss_and_grads(torch.from_numpy(fmap).to(cuda), torch.from_numpy(gts[:, 0].copy()).to(cuda),
+                                 torch.from_numpy(offs).to(cuda))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-4)
+    got = trk.cell.state_dict(grad=True)
+    assert sorted(got) == sorted(grads_ref)
+    for k in sorted(grads_ref):
+        err = _relerr(got[k].numpy(), grads_ref[k])
+        assert err < 2e-3, "%s: relative error %.3e" % (k, err)
+    before = {k: v.clone() for k, v in trk.cell.state_dict().items()}
+    trk.opt.step()
+    torch.cuda.synchronize()
+    after = trk.cell.state_dict()
+    gmax = max(float(np.abs(g).max()) for g in grads_ref.values())
+    for k in before:
+        if float(np.abs(grads_ref[k]).max()) > 1e-3 * gmax:          # a vanishing gradient may not change an fp32 parameter
+            assert float((after[k] - before[k]).abs().max()) > 0, "%s did not move" % k
+    assert all(float((after["lstm/cell_%d/weights" % l] - before["lstm/cell_%d/weights" % l]).abs().max()) > 0 for l in range(layers))
