@@ -354,6 +354,19 @@ int ntk_offset_loss_fwd(const float* logits, const float* offsets, float* pred, 
                         void* stream);
 int ntk_offset_loss_bwd(const float* logits, const float* offsets, float* dlogits, int B, int T, int NF, int O, void* stream);
 
+/* Sequential presentation + heat-map head of main.py's earlier trackers (ntm_sevenbyseven,
+ * main.py:1646-1969; the same serialisation in :979-1291).  Every position of the feature map is a feature
+ * (F = Hf * Wf), rows are [feat(C), feature delimiter, frame delimiter, target, 0 pad]:
+ *   frame 0: F rows [feat_i, 0, 0, gt0_i];  frame t >= 1: one frame-delimiter row, then per feature the rows
+ *   [feat_i, 0, 0, 0] and [0.., 1, 0, 0]  ->  S = F + (T - 1)(2 F + 1) steps (main.py:1701-1775).
+ * fmap [B*T, F, C] (C a multiple of 4), gts0 [B, F] (nullable), X [B, S, ldx] (ldx >= C + 3, multiple of 4).
+ * Loss (main.py:1880-1922): the cell has output_dim 1; the logits at the FEATURE-DELIMITER steps of frames 1..T-1 form
+ * an F-way score vector per frame; loss = sum softmax_cross_entropy_with_logits(scores, gt[b, t]) / (T - 1).
+ * logits [B, S] (= [B,S,1]), gt [B, T-1, F] soft labels; probs [B, T-1, F] (nullable), loss [1], dlogits [B, S] (nullable). */
+int ntk_serialize_sequential(const float* fmap, const float* gts0, float* X, int B, int T, int F, int C, int ldx, void* stream);
+int ntk_heatmap_ce_loss(const float* logits, const float* gt, float* probs, float* loss, float* dlogits,
+                        int B, int T, int F, void* stream);
+
 /* copy-task head (main.py:1603-1610, BASELINE configs[0]): loss = tf.losses.log_loss(labels,
  * sigmoid(logits)) (mean over all n elements, epsilon 1e-7) and d loss / d logits (nullable). */
 int ntk_log_loss(const float* logits, const float* labels, float* loss, float* dlogits, int n, void* stream);

@@ -90,9 +90,14 @@ __device__ __attribute__((aligned(16))) float g_wino_zero[WINO_MAX_CIN] = {0.f};
 template <bool POOL, int TW, int TH, int NSUB>
 __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 2 * TW + 2, PH = 2 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
+    // LDS strides of the patch image, in pixels: a patch row is padded from PW to PWS and a sub-block from PWS * PH to
+    // SPXS so that the sixteen lanes of every ds_read_b128 lane group of the transform's window reads fall on sixteen
+    // different 16-byte bank slots (scripts/dev_wino_lds_model.py: 256 -> 128 LDS cycles per K step; un-padded, every
+    // group was 2-way conflicted: the 26-32 % SQ_LDS_BANK_CONFLICT share of profiles/r01_vgg_trunk_winograd_issue_lds_pmc.csv)
+    constexpr int PWS = TW == 8 ? 24 : (TW == 4 ? 12 : PW), SPXS = TW == 2 ? 40 : PWS * PH, NPXS = NSUB * SPXS;
     constexpr int NST = (NPX * 2 + WT - 1) / WT;                      // float4 staging slots per thread (2 per pixel)
-    constexpr int RAWSZ = NPX * RSR2, VSZ = 16 * 32 * RSV2;            // (+16 floats of scratch per patch buffer)
-    static_assert(NTILE <= 32 && NPX <= 288, "tile block");
+    constexpr int RAWSZ = NPXS * RSR2, VSZ = 16 * 32 * RSV2;           // (+16 floats of scratch per patch buffer)
+    static_assert(NTILE <= 32 && NPX <= 288 && NPXS <= 320, "tile block");
     __shared__ __attribute__((aligned(16))) float s_raw[2 * (RAWSZ + 16)];  // 2 x 8.6-13.8 KB
     __shared__ __attribute__((aligned(16))) float s_V[2 * VSZ];             // 2 x 16 KB (32 KB: also the epilogue's Z)
 
@@ -132,14 +137,14 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int k = 0; k < NST; ++k) {
         const int s = tid + k * WT;
         const int px = s >> 1, c4 = s & 1;
-        dst[k] = (NPX * RSR2) / 4 + (tid & 3);          // scratch (4 float4 behind each patch buffer)
+        dst[k] = (NPXS * RSR2) / 4 + (tid & 3);         // scratch (4 float4 behind each patch buffer)
         src[k] = g_wino_zero;
         if (px < NPX) {
             const int q = px / SPX, lp = px - q * SPX;
             const int pr = lp / PW, pc = lp - pr * PW;
             const int fq = s_sbf[q];
             const int y = s_sby[q] - 1 + pr, x = s_sbx[q] - 1 + pc;
-            dst[k] = px * (RSR2 / 4) + c4;
+            dst[k] = (q * SPXS + pr * PWS + pc) * (RSR2 / 4) + c4;
             if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) src[k] = a.in + (((size_t)fq * H + y) * W + x) * Cin + c4 * 4;
         }
     }
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
     const int pt_rA = (wave == 0) ? 0 : (wave == 2 ? 2 : 1), pt_rB = (wave == 0) ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float pt_sg = (wave == 1) ? 1.f : -1.f;        // t = d[rA] + sg d[rB]: i0 r0-r2, i1 r1+r2, i2 r2-r1, i3 r1-r3
     // lanes of tile rows >= NTILE transform window 0 into their own (unused) V rows: no divergence
-    const int pt_ra = pt_on ? (pt_q * SPX + (2 * pt_tr + pt_rA) * PW + 2 * pt_tc) * RSR2 + pt_c4 * 4 : pt_c4 * 4;
-    const int pt_rb = pt_on ? (pt_q * SPX + (2 * pt_tr + pt_rB) * PW + 2 * pt_tc) * RSR2 + pt_c4 * 4 : pt_c4 * 4;
+    const int pt_ra = pt_on ? (pt_q * SPXS + (2 * pt_tr + pt_rA) * PWS + 2 * pt_tc) * RSR2 + pt_c4 * 4 : pt_c4 * 4;
+    const int pt_rb = pt_on ? (pt_q * SPXS + (2 * pt_tr + pt_rB) * PWS + 2 * pt_tc) * RSR2 + pt_c4 * 4 : pt_c4 * 4;
     const int pt_v = ((4 * wave) * 32 + pt_tile) * RSV2 + ((pt_c4 ^ ((pt_tile >> 3) & 1)) * 4);
 
     // ---- MFMA role

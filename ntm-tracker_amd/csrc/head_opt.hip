@@ -77,6 +77,89 @@ __global__ __launch_bounds__(1024) void offset_loss_kernel(const float* __restri
     }
 }
 
+// Sequential presentation of main.py's heat-map trackers (ntm_sevenbyseven, main.py:1701-1775; the same layout in
+// :979-1291): every position of the feature map is a feature (F = Hf * Wf), rows are [feat(C), feature delimiter,
+// frame delimiter, target]:
+//   frame 0      : F rows [feat_i, 0, 0, gt0_i]
+//   frame t >= 1 : one frame-delimiter row [0.., 0, 1, 0], then per feature [feat_i, 0, 0, 0] and [0.., 1, 0, 0]
+// -> S = F + (T - 1) (2 F + 1) rows.  One 128-thread workgroup per row.
+__global__ void serialize_sequential_kernel(const float* __restrict__ fmap, const float* __restrict__ gts0,
+                                            float* __restrict__ X, int T, int F, int C, int ldx) {
+    const int S = F + (T - 1) * (2 * F + 1);
+    const int row = blockIdx.x, b = row / S, s = row - b * S;
+    int t = 0, i = s, kind = 0;                 // kind 0: feature row, 1: feature delimiter, 2: frame delimiter
+    if (s >= F) {
+        const int r = s - F;
+        t = 1 + r / (2 * F + 1);
+        const int p = r % (2 * F + 1);
+        if (p == 0) { kind = 2; i = 0; }
+        else { i = (p - 1) >> 1; kind = ((p - 1) & 1) ? 1 : 0; }
+    }
+    float* xr = X + (size_t)row * ldx;
+    const int C4 = C >> 2;
+    f32x4* dst = reinterpret_cast<f32x4*>(xr);
+    if (kind == 0) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(fmap + (((size_t)b * T + t) * F + i) * C);
+        for (int c = threadIdx.x; c < C4; c += blockDim.x) dst[c] = src[c];
+    } else {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int c = threadIdx.x; c < C4; c += blockDim.x) dst[c] = z;
+    }
+    for (int c = C + threadIdx.x; c < ldx; c += blockDim.x) {
+        float v = 0.f;
+        if (c == C) v = kind == 1 ? 1.f : 0.f;
+        else if (c == C + 1) v = kind == 2 ? 1.f : 0.f;
+        else if (c == C + 2) v = (t == 0 && gts0) ? gts0[(size_t)b * F + i] : 0.f;
+        xr[c] = v;
+    }
+}
+
+// Heat-map head of the sequential trackers (main.py:1880-1922): the logit (output_dim 1) at each FEATURE-DELIMITER step of
+// frames 1..T-1 is one entry of that frame's F-way score vector; loss = sum_{b,t} softmax_cross_entropy(scores, gt[b,t]) /
+// (T - 1).  One wave per (b, t >= 1): softmax over F, cross entropy against the (soft) labels, and the gradient
+// (softmax * sum(labels) - labels) / (T - 1) scattered to the gathered steps (zero elsewhere; dlogits zeroed first).
+__global__ __launch_bounds__(1024) void heatmap_ce_loss_kernel(const float* __restrict__ logits, const float* __restrict__ gt,
+                                                                float* __restrict__ probs, float* __restrict__ loss,
+                                                                float* __restrict__ dlogits, int B, int T, int F) {
+    __shared__ float red[16];
+    const int S = F + (T - 1) * (2 * F + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (dlogits) {
+        for (size_t i = tid; i < (size_t)B * S; i += blockDim.x) dlogits[i] = 0.f;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    const float inv = 1.0f / (float)(T - 1);
+    for (int bt = wave; bt < B * (T - 1); bt += nw) {
+        const int b = bt / (T - 1), t = bt % (T - 1) + 1;
+        const size_t base = (size_t)b * S + F + (size_t)(t - 1) * (2 * F + 1) + 1;      // first feature row of frame t
+        const float* lab = gt + ((size_t)b * (T - 1) + (t - 1)) * F;
+        float mx = -INFINITY;
+        for (int i = lane; i < F; i += 64) mx = fmaxf(mx, logits[base + 2 * i + 1]);
+        mx = wave_max(mx);
+        float se = 0.f, sl = 0.f, dotl = 0.f;
+        for (int i = lane; i < F; i += 64) {
+            const float z = logits[base + 2 * i + 1] - mx, y = lab[i];
+            se += expf(z); sl += y; dotl += y * z;
+        }
+        se = wave_sum(se); sl = wave_sum(sl); dotl = wave_sum(dotl);
+        const float lse = logf(se);
+        if (lane == 0) acc += sl * lse - dotl;                   // -sum y (z - lse)
+        for (int i = lane; i < F; i += 64) {
+            const float p = expf(logits[base + 2 * i + 1] - mx - lse);
+            if (probs) probs[((size_t)b * (T - 1) + (t - 1)) * F + i] = p;
+            if (dlogits) dlogits[base + 2 * i + 1] = (p * sl - lab[i]) * inv;
+        }
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += red[w];
+        if (loss) *loss = s * inv;
+    }
+}
+
 // copy task head (main.py:1603-1610): p = sigmoid(logit); loss = mean(-(y log(p+eps) + (1-y) log(1-p+eps))), eps = 1e-7
 // (tf.losses.log_loss defaults); dlogits = d loss / d logit.  Single workgroup, fixed-order reduction.
 __global__ __launch_bounds__(1024) void log_loss_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
@@ -285,6 +368,28 @@ extern "C" int ntk_log_loss(const float* logits, const float* labels, float* los
     NTK_REQUIRE(n > 0, NTK_ERR_BAD_SHAPE, "ntk_log_loss: n=%d", n);
     log_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, labels, loss, dlogits, n);
     NTK_CHECK_LAUNCH("ntk_log_loss");
+    return NTK_OK;
+}
+
+extern "C" int ntk_serialize_sequential(const float* fmap, const float* gts0, float* X, int B, int T, int F, int C, int ldx,
+                                        void* stream) {
+    NTK_REQUIRE(fmap && X, NTK_ERR_BAD_PTR, "ntk_serialize_sequential: null pointer");
+    NTK_REQUIRE(B > 0 && T > 0 && F > 0 && C > 0 && (C % 4) == 0 && ldx >= C + 3 && (ldx % 4) == 0, NTK_ERR_BAD_SHAPE,
+                "ntk_serialize_sequential: B=%d T=%d F=%d C=%d (multiple of 4) ldx=%d (>= C + 3, multiple of 4)", B, T, F, C, ldx);
+    NTK_REQUIRE(ntk_aligned16(fmap) && ntk_aligned16(X), NTK_ERR_BAD_PTR, "ntk_serialize_sequential: 16-byte alignment");
+    const long rows = (long)B * (F + (long)(T - 1) * (2 * F + 1));
+    NTK_REQUIRE(rows < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_serialize_sequential: too many rows");
+    serialize_sequential_kernel<<<(unsigned)rows, 128, 0, (hipStream_t)stream>>>(fmap, gts0, X, T, F, C, ldx);
+    NTK_CHECK_LAUNCH("ntk_serialize_sequential");
+    return NTK_OK;
+}
+
+extern "C" int ntk_heatmap_ce_loss(const float* logits, const float* gt, float* probs, float* loss, float* dlogits,
+                                   int B, int T, int F, void* stream) {
+    NTK_REQUIRE(logits && gt && (loss || dlogits || probs), NTK_ERR_BAD_PTR, "ntk_heatmap_ce_loss: null pointer");
+    NTK_REQUIRE(B > 0 && T >= 2 && F > 0, NTK_ERR_BAD_SHAPE, "ntk_heatmap_ce_loss: B=%d T=%d (>= 2) F=%d", B, T, F);
+    heatmap_ce_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, gt, probs, loss, dlogits, B, T, F);
+    NTK_CHECK_LAUNCH("ntk_heatmap_ce_loss");
     return NTK_OK;
 }
 

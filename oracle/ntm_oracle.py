@@ -319,6 +319,39 @@ def serialize_inputs(features, gts):
     return np.concatenate([padded, target[:, :, None]], axis=2)                  # :498
 
 
+def serialize_sequential(features, gts):
+    """main.py:1701-1775 (ntm_sevenbyseven; the same layout in :979-1291).  features [B,T,F,C], gts [B,T,F].
+    Returns [B, F + (T-1)(2F+1), C+3]: columns [feat, feature delimiter, frame delimiter, target]."""
+    B, T, F, C = features.shape
+    dt = features.dtype
+    padded = np.concatenate([features, np.zeros((B, T, F, 2), dt)], axis=3)                     # :1718-1719
+    rest = padded[:, 1:]                                                                        # :1721
+    frame_delim = np.zeros((B, T - 1, 1, C + 2), dt); frame_delim[..., C + 1] = 1.0             # :1725-1734
+    feat_delim = np.zeros((B, T - 1, F, C + 2), dt); feat_delim[..., C] = 1.0                   # :1735-1744
+    rest = np.concatenate([rest, feat_delim], axis=3).reshape(B, T - 1, 2 * F, C + 2)           # :1746-1750
+    rest = np.concatenate([frame_delim, rest], axis=2).reshape(B, (T - 1) * (2 * F + 1), C + 2)  # :1752-1760
+    x = np.concatenate([padded[:, 0], rest], axis=1)                                            # :1764-1767
+    target = np.concatenate([gts[:, 0, :].astype(dt), np.zeros((B, (T - 1) * (2 * F + 1)), dt)], axis=1)   # :1768-1772
+    return np.concatenate([x, target[:, :, None]], axis=2)                                      # :1774-1776
+
+
+def heatmap_gather(logits, T, F):
+    """main.py:1880-1897: logits [B,S,1] -> scores [B,T-1,F] (the feature-delimiter step of every feature)."""
+    B = logits.shape[0]
+    g = logits.reshape(B, -1)[:, F:]
+    g = g.reshape(B, T - 1, 2 * F + 1)[:, :, 1:]
+    return g.reshape(B, T - 1, F, 2)[:, :, :, 1]
+
+
+def heatmap_ce_loss(logits, gt, T):
+    """main.py:1919-1923: sum of softmax_cross_entropy_with_logits(scores, gt) / (T-1).  Returns (loss, softmax)."""
+    F = gt.shape[2]
+    z = heatmap_gather(logits, T, F).astype(np.float64)
+    z = z - z.max(axis=2, keepdims=True)
+    lse = np.log(np.exp(z).sum(axis=2, keepdims=True))
+    return float(-(gt * (z - lse)).sum() / (T - 1)), np.exp(z - lse)
+
+
 def offset_loss(logits, offsets, num_features=64):
     """direct_offset_output.py:581-606.  logits [B,S,2], offsets [B,T,2].
     Returns (loss, pred [B,T-1,2])."""

@@ -204,3 +204,27 @@ def test_golden_ntm_step_c2_and_vgg():
     ws = O.init_vgg_weights(np.random.default_rng(int(v["seed"])))
     f = O.vgg16_conv43(v["frame"], ws)
     np.testing.assert_allclose(f, v["conv4_3"], rtol=1e-4, atol=1e-4 * np.abs(v["conv4_3"]).max())
+
+
+def test_sequential_serialisation_layout():
+    """main.py:1701-1775: S = F + (T-1)(2F+1); frame 0 = F feature rows carrying the target; later frames = frame delimiter,
+    then (feature, feature delimiter) pairs; the heat-map gather (main.py:1880-1897) picks the feature-delimiter steps."""
+    rng = np.random.default_rng(0)
+    B, T, F, C = 2, 3, 4, 5
+    feats = rng.standard_normal((B, T, F, C)).astype(np.float32)
+    gts = rng.uniform(size=(B, T, F)).astype(np.float32)
+    x = O.serialize_sequential(feats, gts)
+    assert x.shape == (B, F + (T - 1) * (2 * F + 1), C + 3)
+    assert np.array_equal(x[:, :F, :C], feats[:, 0]) and np.array_equal(x[:, :F, C + 2], gts[:, 0]) and not x[:, F:, C + 2].any()
+    for t in range(1, T):
+        base = F + (t - 1) * (2 * F + 1)
+        assert np.all(x[:, base, C + 1] == 1) and not x[:, base, :C + 1].any()
+        for i in range(F):
+            assert np.array_equal(x[:, base + 1 + 2 * i, :C], feats[:, t, i]) and not x[:, base + 1 + 2 * i, C:].any()
+            assert np.all(x[:, base + 2 + 2 * i, C] == 1) and not x[:, base + 2 + 2 * i, :C].any()
+    logits = np.arange(B * x.shape[1], dtype=np.float64).reshape(B, -1, 1)
+    g = O.heatmap_gather(logits, T, F)
+    assert g.shape == (B, T - 1, F) and g[0, 0, 0] == F + 2 and g[0, 1, 3] == F + (2 * F + 1) + 2 + 6
+    loss, p = O.heatmap_ce_loss(np.zeros((B, x.shape[1], 1)), np.full((B, T - 1, F), 1.0 / F), T)
+    np.testing.assert_allclose(loss, B * np.log(F))              # uniform scores: (T-1) B log F / (T-1)
+    np.testing.assert_allclose(p, 1.0 / F)
