@@ -298,13 +298,14 @@ int ntk_dnc_access_step_fwd(const float* iface_raw, int ldr, const float* memory
                             float* precedence_out, float* usage_out, float* read_words, float* workspace,
                             int B, int N, int W, int R, int Wn, void* stream);
 
-/* Full BPTT through a recorded DNC sequence (num_writes == 1).  WrT [4*hid][ldkT], WiT [IP][ldhT]
+/* Full BPTT through a recorded DNC sequence (num_writes 1..4: one write head runs the tuned kernel, 2..4 the
+ * general one).  WrT [4*hid][ldkT], WiT [IP][ldhT]
  * are transposed copies of Wr / Wi; *0 pointers are the state BEFORE step 0; gM [B,N,W] and
- * gL [B,N,N] are zero-initialised scratch.  Out: raw gate gradients dgates [B,S,4*hid], raw
+ * gL [B,Wn,N,N] are zero-initialised scratch.  Out: raw gate gradients dgates [B,S,4*hid], raw
  * interface gradients dxi [B,S,IP], gradient of the pre-clip output dypre [B,S,OP]; weight
  * gradients follow as ntk_gemm_tn_f32 over the recorded rows.
  * Segmented BPTT (long sequences, config 5): run the segments last to first, re-recording each from its
- * checkpointed state; gM / gL are NOT re-zeroed between segments and gcarry [B, 2N + R*N + ldkT + hid]
+ * checkpointed state; gM / gL are NOT re-zeroed between segments and gcarry [B, (Wn+1)*N + R*N + ldkT + hid]
  * (optional, may be null) carries the remaining state gradients: read when carry_in != 0, always written. */
 int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value,
                     const float* WrT, int ldkT, const float* WiT, int ldhT, const float* Wy,

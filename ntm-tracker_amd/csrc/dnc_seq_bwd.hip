@@ -3,7 +3,8 @@
 // direct_offset_output_with_dnc.py:615-620).  One persistent 1024-thread workgroup per sequence walks the
 // steps in reverse.  Carried gradients: memory (N x W) and link (N x N) in global scratch, everything else
 // (precedence, usage, read weights, reads, LSTM h/c) in LDS.  Single write head (num_writes == 1, the
-// reference default and every benchmark config); up to 4 read heads.
+// reference default and every benchmark config); up to 4 read heads.  ntk_dnc_seq_bwd hands 2..4 write heads to
+// the general kernel in dnc_seq_bwd_mw.hip.
 //
 // Non-differentiable edges of the reference: write weights enter the usage update under
 // tf.stop_gradient (addressing.py:302); the allocation sort passes gradient to the sorted VALUES only
@@ -15,7 +16,7 @@
 // [B,S,OP]; the weight gradients are k-major GEMMs over those rows (ntk_gemm_tn_f32).
 // Column sums of the link pass use LDS float atomics (summation order across waves is not fixed:
 // gradients are reproducible to rounding, not bitwise).
-#include "dnc_common.h"
+#include "dnc_bwd_args.h"
 
 // The allocation gradient re-derives the usage ORDER of the forward pass from the recorded usages.  The forward
 // kernel evaluates nonusage = 1 - (eps + (1 - eps) u) op by op (no fused multiply-add); with contraction on, this
@@ -23,22 +24,6 @@
 // and the usage / free-gate gradients come out wrong by orders of magnitude (found by the per-step gradient probe
 // scripts/dev_dnc_stepgrad.py: free_gate 1e-7 -> 8.7e-15 absolute error once the rounding matches).
 #pragma clang fp contract(off)
-
-struct DncBwdArgs {
-    DncDims d;
-    const float* WrT; int ldkT;      // [4*hid][ldkT]
-    const float* WiT; int ldhT;      // [IP][ldhT]
-    const float* Wy;                 // [ldy][OP]
-    const float* mem0; const float* link0; const float* usage0; const float* rw0; const float* ww0;
-    const float* prec0; const float* hc0;
-    const float* rec_gates; const float* rec_c; const float* rec_ifc; const float* rec_u; const float* rec_ww;
-    const float* rec_rw; const float* rec_cw; const float* rec_cr; const float* rec_al; const float* rec_p;
-    const float* rec_fwd; const float* rec_bwd; const float* rec_M; const float* rec_L; const float* rec_ypre;
-    const float* dout;               // [B,S,O]
-    float* gM; float* gL;            // [B,N,W], [B,N,N] zero-initialised scratch (carried gradients)
-    float* dgates; float* dxi; float* dypre;
-    float* gcarry; int carry_in;     // [B, 2N + R*N + ldkT + hid] gradients carried into state t=-1 (segmented BPTT)
-};
 
 struct DncBwdLds {
     int part, I, DX, WW, WWp, U, Up, Pp, CW, AL, NM, NMw, SIMw, DWW, DCW, DA, gP, DPp, gU, gUn,
@@ -584,7 +569,7 @@ extern "C" int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hi
     DncBwdArgs a;
     dnc_fill_dims(a.d, B, S, N, W, R, Wn, hid, O, clip_value);
     NTK_REQUIRE(B > 0 && S > 0, NTK_ERR_BAD_SHAPE, "ntk_dnc_seq_bwd: B=%d S=%d", B, S);
-    NTK_REQUIRE(Wn == 1, NTK_ERR_UNSUPPORTED, "ntk_dnc_seq_bwd: num_writes=%d (the BPTT kernel implements one write head)", Wn);
+    NTK_REQUIRE(Wn >= 1 && Wn <= 4, NTK_ERR_UNSUPPORTED, "ntk_dnc_seq_bwd: num_writes=%d (the BPTT kernels implement 1..4 write heads)", Wn);
     NTK_REQUIRE(N >= 4 && (N % 4) == 0 && N <= DT && W >= 4 && (W % 4) == 0 && W <= 256 && R >= 1 && R <= 4,
                 NTK_ERR_UNSUPPORTED, "ntk_dnc_seq_bwd: N=%d W=%d R=%d unsupported", N, W, R);
     NTK_REQUIRE(hid >= 4 && (hid % 4) == 0 && hid <= DT && R * W <= DT && O >= 1 && O <= 16, NTK_ERR_UNSUPPORTED,
@@ -605,6 +590,7 @@ extern "C" int ntk_dnc_seq_bwd(int B, int S, int N, int W, int R, int Wn, int hi
     a.rec_cw = rec_cw; a.rec_cr = rec_cr; a.rec_al = rec_al; a.rec_p = rec_p; a.rec_fwd = rec_fwd; a.rec_bwd = rec_bwd;
     a.rec_M = rec_M; a.rec_L = rec_L; a.rec_ypre = rec_ypre; a.dout = dout; a.gM = gM; a.gL = gL;
     a.dgates = dgates; a.dxi = dxi; a.dypre = dypre; a.gcarry = gcarry; a.carry_in = carry_in;
+    if (Wn > 1) return dnc_seq_bwd_mw_launch(a, (hipStream_t)stream);      // general kernel (dnc_seq_bwd_mw.hip)
     DncBwdLds L;
     dnc_bwd_lds(a.d, ldkT, ldhT, L);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);

@@ -55,7 +55,12 @@ class DNC(object):
     def __init__(self, access_config, controller_config, output_size, clip_value=None, input_dim=None,
                  device="cuda", seed=0):
         self.N = int(access_config.get("memory_size", 128))
-        self.W = int(access_config.get("word_size", 20))
+        #: word_size as the caller sees it; the kernels work on words zero padded to a multiple of 4 floats (self.W):
+        #: padded interface columns have zero weights (write / key entries 0; erase sigmoid(0) acts on zeros only), so
+        #: the padded memory columns stay zero and every result is unchanged (the reference's own DNC test shape is
+        #: word_size 6, dnc/access_test.py:28-34)
+        self.word_size = int(access_config.get("word_size", 20))
+        self.W = (self.word_size + 3) // 4 * 4
         self.R = int(access_config.get("num_reads", 1))
         self.Wn = int(access_config.get("num_writes", 1))
         self.hid = int(controller_config["hidden_size"])
@@ -72,8 +77,8 @@ class DNC(object):
             self._build(int(input_dim))
 
     # ---- parameters (Sonnet v1 names)
-    def interface_widths(self):
-        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+    def interface_widths(self, logical=False):
+        N, W, R, Wn = self.N, (self.word_size if logical else self.W), self.R, self.Wn
         return dict(write_vectors=Wn * W, erase_vectors=Wn * W, free_gate=R, allocation_gate=Wn, write_gate=Wn,
                     read_mode=R * (1 + 2 * Wn), write_keys=Wn * W, write_strengths=Wn, read_keys=R * W, read_strengths=R)
 
@@ -83,17 +88,81 @@ class DNC(object):
         if sd is None:
             g = torch.Generator().manual_seed(int(self.seed))
             tn = lambda fan_in, *shape: torch.clamp(torch.randn(shape, generator=g), -2, 2) / fan_in ** 0.5
-            in_dim = input_dim + self.R * self.W + self.hid
+            in_dim = input_dim + self.R * self.word_size + self.hid
             sd = {"lstm/w_gates": tn(in_dim, in_dim, 4 * self.hid), "lstm/b_gates": torch.zeros(4 * self.hid)}
-            for name, width in self.interface_widths().items():
+            for name, width in self.interface_widths(logical=True).items():
                 sd["memory_access/%s/w" % name] = tn(self.hid, self.hid, width)
                 sd["memory_access/%s/b" % name] = torch.zeros(width)
-            sd["output_linear/w"] = tn(self.Ky, self.Ky, self.O)
+            ky = self.hid + self.R * self.word_size
+            sd["output_linear/w"] = tn(ky, ky, self.O)
             sd["output_linear/b"] = torch.zeros(self.O)
         self.load_state_dict(sd, input_dim)
 
+    # ---- word padding (word_size -> multiple of 4) of the reference-layout variables
+    _WORD_FIELDS = {"write_vectors": "Wn", "erase_vectors": "Wn", "write_keys": "Wn", "read_keys": "R"}
+
+    def _words_cols(self, M, groups, pad):
+        """[..., groups * W_from] -> [..., groups * W_to] along the last axis (zero fill / strip)."""
+        Wl, Wp = self.word_size, self.W
+        if Wl == Wp:
+            return M
+        a, b = (Wl, Wp) if pad else (Wp, Wl)
+        out = M.new_zeros(M.shape[:-1] + (groups * b,))
+        out.view(M.shape[:-1] + (groups, b))[..., :min(a, b)] = M.reshape(M.shape[:-1] + (groups, a))[..., :min(a, b)]
+        return out
+
+    def _pad_sd(self, sd):
+        t = lambda v: torch.as_tensor(v, dtype=torch.float32)
+        if self.word_size == self.W:
+            return {k: t(v) for k, v in sd.items()}
+        hid, R = self.hid, self.R
+        out = {k: t(v) for k, v in sd.items()}
+        Wg = out["lstm/w_gates"]
+        D = Wg.shape[0] - R * self.word_size - hid
+        out["lstm/w_gates"] = torch.cat([Wg[:D], self._words_cols(Wg[D:D + R * self.word_size].t(), R, True).t(), Wg[D + R * self.word_size:]], 0)
+        for name, grp in self._WORD_FIELDS.items():
+            g = self.Wn if grp == "Wn" else R
+            out["memory_access/%s/w" % name] = self._words_cols(out["memory_access/%s/w" % name], g, True)
+            out["memory_access/%s/b" % name] = self._words_cols(out["memory_access/%s/b" % name], g, True)
+        Wo = out["output_linear/w"]
+        out["output_linear/w"] = torch.cat([Wo[:hid], self._words_cols(Wo[hid:].t(), R, True).t()], 0)
+        return out
+
+    def _strip_sd(self, sd):
+        if self.word_size == self.W:
+            return sd
+        hid, R = self.hid, self.R
+        out = dict(sd)
+        Wg = out["lstm/w_gates"]
+        D = Wg.shape[0] - R * self.W - hid
+        out["lstm/w_gates"] = torch.cat([Wg[:D], self._words_cols(Wg[D:D + R * self.W].t().contiguous(), R, False).t(), Wg[D + R * self.W:]], 0).contiguous()
+        for name, grp in self._WORD_FIELDS.items():
+            g = self.Wn if grp == "Wn" else R
+            out["memory_access/%s/w" % name] = self._words_cols(out["memory_access/%s/w" % name], g, False)
+            out["memory_access/%s/b" % name] = self._words_cols(out["memory_access/%s/b" % name], g, False)
+        Wo = out["output_linear/w"]
+        out["output_linear/w"] = torch.cat([Wo[:hid], self._words_cols(Wo[hid:].t().contiguous(), R, False).t()], 0).contiguous()
+        return out
+
+    def _pad_state(self, st):
+        if st is None or self.word_size == self.W:
+            return st
+        acc = st.access_state
+        return DNCState(self._words_cols(st.access_output, 1, True),
+                        AccessState(self._words_cols(acc.memory, 1, True), acc.read_weights, acc.write_weights, acc.linkage, acc.usage),
+                        st.controller_state)
+
+    def _strip_state(self, st):
+        if self.word_size == self.W:
+            return st
+        acc = st.access_state
+        return DNCState(self._words_cols(st.access_output, 1, False),
+                        AccessState(self._words_cols(acc.memory, 1, False), acc.read_weights, acc.write_weights, acc.linkage, acc.usage),
+                        st.controller_state)
+
     def load_state_dict(self, sd, input_dim=None):
         t = lambda v: torch.as_tensor(v, dtype=torch.float32)
+        sd = self._pad_sd(sd)
         W = t(sd["lstm/w_gates"])
         if input_dim is None:
             input_dim = W.shape[0] - self.R * self.W - self.hid
@@ -147,7 +216,7 @@ class DNC(object):
             o += wd
         out["output_linear/w"] = gWy[:self.Ky, :self.O].contiguous()
         out["output_linear/b"] = gWy[self.Ky, :self.O].contiguous()
-        return out
+        return self._strip_sd(out)
 
     def state_dict(self):
         return {k: v.cpu() for k, v in self._unpack().items()}
@@ -156,7 +225,7 @@ class DNC(object):
     def initial_state(self, batch_size, dtype=torch.float32):
         """dnc.py:129-134: all zeros (not trainable)."""
         z = lambda *s: torch.zeros(s, device=self.device, dtype=torch.float32)
-        B, N, W, R, Wn = batch_size, self.N, self.W, self.R, self.Wn
+        B, N, W, R, Wn = batch_size, self.N, self.word_size, self.R, self.Wn
         return DNCState(
             access_output=z(B, R, W),
             access_state=AccessState(z(B, N, W), z(B, R, N), z(B, Wn, N), TemporalLinkageState(z(B, Wn, N, N), z(B, Wn, N)), z(B, N)),
@@ -164,7 +233,7 @@ class DNC(object):
 
     @property
     def state_size(self):
-        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        N, W, R, Wn = self.N, self.word_size, self.R, self.Wn
         return DNCState(R * W, AccessState((N, W), (R, N), (Wn, N), TemporalLinkageState((Wn, N, N), (Wn, N)), (N,)),
                         LSTMState((self.hid,), (self.hid,)))
 
@@ -292,7 +361,7 @@ class DNC(object):
 
     def run_projected(self, xproj, B, S, prev_state=None, record=False):
         """Sequence kernel on an already projected input (xproj [B*S, 4*hid] = X WxT^T)."""
-        st = prev_state or self.initial_state(B)
+        st = self._pad_state(prev_state or self.initial_state(B))
         seg = self._segment_len(B, S) if record else S
         self.last_initial = st
         self.last_segments = None
@@ -300,7 +369,7 @@ class DNC(object):
             rec = self._alloc_records(B, S) if record else {}
             out, new = self._launch_fwd(xproj, B, S, st, rec)
             self.last_record = rec
-            return out.transpose(0, 1), new          # time-major [S,B,O]
+            return out.transpose(0, 1), self._strip_state(new)          # time-major [S,B,O]
         # segmented: forward without records, one state checkpoint per segment
         xp = xproj.view(B, S, 4 * self.hid)
         out = torch.empty((B, S, self.O), device=self.device)
@@ -313,7 +382,7 @@ class DNC(object):
             out[:, s0:s1] = o
         self.last_record = {}
         self.last_segments = (xp, ckpt, bounds)
-        return out.transpose(0, 1), st
+        return out.transpose(0, 1), self._strip_state(st)
 
     def _launch_bwd(self, B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, gcarry, carry_in):
         dev, hid = self.device, self.hid
@@ -358,8 +427,8 @@ class DNC(object):
         reference's Sonnet variable layout ({name: tensor on device}).  When the forward pass was segmented
         (see record_budget_bytes) each segment is re-recorded from its checkpoint, last segment first; the
         state gradients flow between segments through gM / gL / gcarry."""
-        if self.Wn != 1:
-            raise _lib.NtkError("DNC BPTT on the HIP path implements num_writes == 1 (got %d)" % self.Wn)
+        if not 1 <= self.Wn <= 4:
+            raise _lib.NtkError("DNC BPTT on the HIP path implements 1..4 write heads (got %d)" % self.Wn)
         rec, st0 = self.last_record, self.last_initial
         if not rec and not self.last_segments:
             raise _lib.NtkError("backward_sequence needs a recorded forward pass (record=True)")
@@ -372,14 +441,14 @@ class DNC(object):
         _lib.check(L.ntk_transpose_pad(_P(self.Wr), 4 * hid, _P(WrT), ldkT, self.K, 4 * hid, stream), "ntk_transpose_pad")
         _lib.check(L.ntk_transpose_pad(_P(self.Wi), self.IP, _P(WiT), ldhT, hid, self.IP, stream), "ntk_transpose_pad")
         gM = torch.zeros((B, self.N, self.W), device=dev)
-        gL = torch.zeros((B, self.N, self.N), device=dev)
+        gL = torch.zeros((B, self.Wn, self.N, self.N), device=dev)
         dout = dout.contiguous()
         if not self.last_segments:
             dgates, dxi, dypre = self._launch_bwd(B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, None, False)
             self._weight_grads(X.view(B * S, self.ldx), rec, dgates, dxi, dypre, B * S, False)
             return self._unpack(grad=True)
         xp, ckpt, bounds = self.last_segments
-        gcarry = torch.zeros((B, 2 * self.N + self.R * self.N + ldkT + hid), device=dev)
+        gcarry = torch.zeros((B, (self.Wn + 1) * self.N + self.R * self.N + ldkT + hid), device=dev)
         first = True
         for st, (s0, s1) in zip(reversed(ckpt), reversed(bounds)):
             n = s1 - s0

@@ -14,6 +14,10 @@ CASES = [
     ("no_clip_odd", 12, 2, 40, 12, 3, 2, 24, 0.0, 5, 1, False),
     ("c5_shape_short", 514, 2, 512, 128, 4, 1, 200, 20.0, 3, 1, True),
     ("c3_shape_random_state", 514, 2, 256, 64, 4, 1, 200, 20.0, 4, 2, False),
+    # the reference's own DNC test shape (dnc/access_test.py:28-34: memory 20, word_size 6, 2 reads, 3 writes): word_size is
+    # zero padded to 8 inside the core, the state and the variables keep the reference's shapes
+    ("reference_test_shape_w6", 10, 3, 20, 6, 2, 3, 16, 20.0, 6, 2, False),
+    ("word_size_5_zero_state", 7, 2, 24, 5, 1, 1, 12, 0.0, 5, 3, True),
 ]
 
 
@@ -110,8 +114,11 @@ def test_dnc_step_api_and_state_chaining(cuda):
 def test_dnc_unsupported_shapes_fail_loudly(cuda):
     from ntmtrack.dnc import DNC
     from ntmtrack._lib import NtkError
-    core = DNC({"memory_size": 20, "word_size": 6, "num_reads": 2, "num_writes": 3}, {"hidden_size": 16}, 2, 20, input_dim=10, device=cuda)
-    with pytest.raises(NtkError):                    # word_size 6 is not a multiple of 4 (reference test shape)
+    core = DNC({"memory_size": 18, "word_size": 6, "num_reads": 2, "num_writes": 3}, {"hidden_size": 16}, 2, 20, input_dim=10, device=cuda)
+    with pytest.raises(NtkError):                    # memory_size must be a multiple of 4 (word_size is padded inside the core)
+        core.run_sequence(torch.zeros((2, 1, 10), device=cuda))
+    core = DNC({"memory_size": 20, "word_size": 6, "num_reads": 5, "num_writes": 1}, {"hidden_size": 16}, 2, 20, input_dim=10, device=cuda)
+    with pytest.raises(NtkError):                    # at most 4 read heads
         core.run_sequence(torch.zeros((2, 1, 10), device=cuda))
 
 
@@ -141,22 +148,28 @@ def test_dnc_offset_tracker_pipeline(cuda):
 
 
 BWD_CASES = [
-    # name, D, O, N, W, R, hid, clip, S, B, zero initial state?
-    ("small_random_state", 10, 3, 16, 8, 2, 16, 20.0, 5, 2, False),
-    ("small_zero_state", 12, 2, 32, 12, 3, 24, 20.0, 6, 2, True),
-    ("tight_clip", 10, 2, 16, 8, 2, 16, 0.4, 4, 2, False),
-    ("c3_shape", 514, 2, 256, 64, 4, 200, 20.0, 4, 1, False),
-    ("c5_shape", 514, 2, 512, 128, 4, 200, 20.0, 3, 1, False),
+    # name, D, O, N, W, R, Wn, hid, clip, S, B, zero initial state?
+    ("small_random_state", 10, 3, 16, 8, 2, 1, 16, 20.0, 5, 2, False),
+    ("small_zero_state", 12, 2, 32, 12, 3, 1, 24, 20.0, 6, 2, True),
+    ("tight_clip", 10, 2, 16, 8, 2, 1, 16, 0.4, 4, 2, False),
+    ("c3_shape", 514, 2, 256, 64, 4, 1, 200, 20.0, 4, 1, False),
+    ("c5_shape", 514, 2, 512, 128, 4, 1, 200, 20.0, 3, 1, False),
+    # several write heads (dnc_seq_bwd_mw.hip): the reference's own DNC test shape (memory 20, word 6 -> padded to 8,
+    # 2 reads, 3 writes; dnc/access_test.py:28-34), two heads, four heads on a wider memory
+    ("reference_test_shape_3_writes", 10, 3, 20, 6, 2, 3, 16, 20.0, 6, 2, False),
+    ("two_writes_zero_state", 12, 2, 32, 12, 3, 2, 24, 20.0, 6, 2, True),
+    ("four_writes", 9, 2, 64, 16, 4, 4, 32, 20.0, 5, 2, False),
+    ("three_writes_c3_memory", 514, 2, 256, 64, 4, 3, 200, 20.0, 3, 1, False),
 ]
 
 
-@pytest.mark.parametrize("name,Din,O,N,W,R,hid,clip,S,B,zero", BWD_CASES, ids=[c[0] for c in BWD_CASES])
-def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, hid, clip, S, B, zero):
+@pytest.mark.parametrize("name,Din,O,N,W,R,Wn,hid,clip,S,B,zero", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, Wn, hid, clip, S, B, zero):
     """d(sum(y * G)) / d(params) through S recorded steps vs torch-autograd on the float64 restatement.
     Inputs are chosen without near-tied usages (see _random_state) so the allocation sort is well conditioned."""
     from oracle import dnc_oracle_torch as DT
     from ntmtrack import dnc as G
-    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=1, hidden_size=hid, clip_value=clip)
+    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=Wn, hidden_size=hid, clip_value=clip)
     rng = np.random.default_rng(17)
     p = D.init_params(cfg, rng)
     for k in p:
@@ -180,7 +193,7 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, h
     ys, _ = DT.run_model(cfg, pt, t64(x), ost)
     (ys * t64(Gy)).sum().backward()
 
-    core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, clip, device=cuda)
+    core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": Wn}, {"hidden_size": hid}, O, clip, device=cuda)
     core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
     gst = None
     if st0 is not None:
@@ -191,6 +204,7 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, h
                          G.LSTMState(t(st0.controller_state.hidden), t(st0.controller_state.cell)))
     out, _st = core.run_sequence(torch.from_numpy(x).to(cuda), gst, record=True)
     np.testing.assert_allclose(out.cpu().numpy(), ys.detach().numpy(), atol=5e-5)
+    assert {k: tuple(v.shape) for k, v in core.state_dict().items()} == {k: v.shape for k, v in p.items()}
     dout = torch.from_numpy(np.ascontiguousarray(np.transpose(Gy, (1, 0, 2)))).to(cuda)      # [B,S,O]
     grads = core.backward_sequence(core.last_X, dout)
     torch.cuda.synchronize()
@@ -203,13 +217,15 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, h
     assert not bad, bad
 
 
-def test_dnc_segmented_bptt_equals_whole_sequence(cuda):
+@pytest.mark.parametrize("Wn,W", [(1, 12), (2, 10)], ids=["one_write", "two_writes_w10"])
+def test_dnc_segmented_bptt_equals_whole_sequence(cuda, Wn, W):
     """Long-horizon path (config 5): BPTT in re-recorded segments from state checkpoints gives the gradients of the
-    single recorded pass (same kernels, same order inside a step; only the LDS-atomic column sums may reorder)."""
+    single recorded pass (same kernels, same order inside a step; only the LDS-atomic column sums may reorder).
+    The two-head case carries one precedence gradient per head between segments and a padded word size."""
     from ntmtrack import dnc as G
     rng = np.random.default_rng(23)
-    N, W, R, hid, O, Din, S, B = 32, 12, 3, 24, 2, 20, 13, 3
-    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=1, hidden_size=hid, clip_value=20.0)
+    N, R, hid, O, Din, S, B = 32, 3, 24, 2, 20, 13, 3
+    cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=Wn, hidden_size=hid, clip_value=20.0)
     p = D.init_params(cfg, rng)
     for k in p:
         if k.startswith("memory_access/") and k.endswith("/w"):
@@ -218,7 +234,7 @@ def test_dnc_segmented_bptt_equals_whole_sequence(cuda):
     dout = torch.from_numpy(rng.standard_normal((B, S, O)).astype(np.float32)).to(cuda)
     res = {}
     for seg in (None, 5, 1):
-        core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, 20.0, device=cuda)
+        core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": Wn}, {"hidden_size": hid}, O, 20.0, device=cuda)
         core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
         core.bptt_segment = seg
         out, st = core.run_sequence(x, None, record=True)
