@@ -22,6 +22,12 @@
 
 #ifndef WINO_UD
 #define WINO_UD 3      // U prefetch distance in planes (1..3)
+// Ablation switches for scripts/dev_wino_ablate.sh (results are WRONG with any of them set; never defined in the
+// product build): bit 0 no U loads in the K loop, bit 1 no input transform, bit 2 no patch staging, bit 3 no
+// workgroup barrier in the K loop, bit 4 no A-operand reads.
+#ifndef WINO_ABL
+#define WINO_ABL 0
+#endif
 #endif
 
 namespace {
@@ -236,22 +242,27 @@ __global__ __launch_bounds__(WT, 2) void conv3x3_wino_kernel(WinoArgs a) {
 
     for (int c8 = 0; c8 < n8; ++c8) {
         const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;                 // next chunk (wraps on the last iteration)
-        store_patch((c8 + 1) & 1);
-        __syncthreads();
-        load_patch(c8 + 3 < n8 ? KC2 : 0);                         // requests patch min(c8 + 2, n8 - 1)
+        if constexpr (!(WINO_ABL & 4)) store_patch((c8 + 1) & 1);
+        if constexpr (!(WINO_ABL & 8)) __syncthreads();
+        if constexpr (!(WINO_ABL & 4)) load_patch(c8 + 3 < n8 ? KC2 : 0);   // requests patch min(c8 + 2, n8 - 1)
         const float* uc = ubase + (size_t)c8 * 8192;
         const float* un = ubase + (size_t)cn * 8192;
         const float* vcur = s_V + (c8 & 1) * VSZ + va;
-        Aq[0] = *reinterpret_cast<const f32x4*>(vcur);
+        if constexpr (!(WINO_ABL & 16)) Aq[0] = *reinterpret_cast<const f32x4*>(vcur);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int jn = j + UD;                                  // plane requested now
             const float* up = (jn < 4) ? uc + jn * 512 : un + (jn - 4) * 512;
-            Bq[jn & 3][0] = *reinterpret_cast<const f32x4*>(up + ulane);
-            Bq[jn & 3][1] = *reinterpret_cast<const f32x4*>(up + 256 + ulane);
-            if (j < 3) Aq[(j + 1) & 1] = *reinterpret_cast<const f32x4*>(vcur + (j + 1) * 32 * RSV2);
-            if (j == 0) tr_load((c8 + 1) & 1);          // next chunk's window reads ...
-            if (j == 2) tr_store((c8 + 1) & 1);         // ... become its V two planes of MFMAs later
+            if constexpr (!(WINO_ABL & 1)) {
+                Bq[jn & 3][0] = *reinterpret_cast<const f32x4*>(up + ulane);
+                Bq[jn & 3][1] = *reinterpret_cast<const f32x4*>(up + 256 + ulane);
+            }
+            if constexpr (!(WINO_ABL & 16))
+                if (j < 3) Aq[(j + 1) & 1] = *reinterpret_cast<const f32x4*>(vcur + (j + 1) * 32 * RSV2);
+            if constexpr (!(WINO_ABL & 2)) {
+                if (j == 0) tr_load((c8 + 1) & 1);          // next chunk's window reads ...
+                if (j == 2) tr_store((c8 + 1) & 1);         // ... become its V two planes of MFMAs later
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
