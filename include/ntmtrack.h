@@ -82,6 +82,15 @@ int ntk_vgg_pack_weights_wino(const float* w_hwio, float* u_packed, int cin, int
 int ntk_vgg_conv3x3_relu_wino_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                   int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream);
 
+/* The same operator by fused Winograd F(4x4,3x3) (csrc/conv_wino43.hip): 36 transform planes, 4x fewer multiplies
+ * than the direct form; fp32 rounding error ~16x that of F(2x2,3x3) (4e-6 .. 9e-6 of the activation scale per layer),
+ * inside the 1e-4 bound of the path.  cin multiple of 16, cout multiple of 64 (cout/64 dividing or a multiple of 8),
+ * H and W multiples of 4.  ntk_vgg_wino43_packed_floats(cin, cout) = 36*cin*cout floats. */
+size_t ntk_vgg_wino43_packed_floats(int cin, int cout);
+int ntk_vgg_pack_weights_wino43(const float* w_hwio, float* u_packed, int cin, int cout, void* stream);
+int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                    int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream);
+
 /* slim.max_pool2d [2,2] stride 2 on NHWC fp32 (vgg.py:155-161) as its own launch (ntk_maxpool2x2).
  * The trunk fuses the pool into the epilogue of conv1_2 / conv2_2 / conv3_3 (fuse_pool); this entry point is the
  * un-fused form with identical results.  H, W even; C a multiple of 4. */

@@ -1,0 +1,435 @@
+// VGG 3x3 convolution as fused Winograd F(4x4,3x3) on the fp32 MFMA pipe (gfx950).
+//
+// out = relu(conv3x3_same(in, w) + b) [+ 2x2/2 max pool] -- the same operator as mfma_f32.hip / conv_wino.hip
+// (vgg.py:155-161 via slim.conv2d).  Every 4x4 output tile is
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray, interpolation points 0, +-1, +-2, inf),
+// summed over input channels: 36 independent GEMMs  M_p[tile, cout] = sum_c V_p[tile, c] U_p[c, cout], p = 6 i + j --
+// 4x fewer multiplies than the direct form (F(2x2,3x3): 2.25x).  fp32 rounding error is ~16x that of F(2x2,3x3)
+// (4e-6 .. 9e-6 of the activation scale per layer, scripts/dev_wino43_numerics.py), inside the 1e-4 bound of the path.
+//
+// Why this shape of kernel.  Measured on gfx950 (scripts/probe/mfma_coissue_probe.hip, SQ_VALU_MFMA_COEXEC_CYCLES = 0):
+// v_mfma_f32_32x32x2_f32 and ordinary VALU / LDS / VMEM instruction issue exclude each other on a SIMD, so a SIMD's time is
+// the SUM of its MFMA cycles and everything else it issues.  F(4x4) cuts the MFMA cycles per output by 1.78x at about
+// the same transform arithmetic per output.  36 planes x (32 tiles x 64 channels) of accumulators are 288 KB: exactly ONE
+// such block fits a CU's register file, so a workgroup is 4 waves, ONE PER SIMD, each with up to 512 registers
+// (9 planes x 2 column blocks x 16 = 288 accumulators), one workgroup per CU.
+//
+//   wave w multiplies planes 9w .. 9w+8.  A operand (V_p) from LDS, B operand (U_p) from global memory, lane-major
+//     packed, requested one whole K step (8 input channels) ahead.
+//   input transform: per K step four tasks, one per wave: plane rows (1,2) and (3,4) (pairs share their row pass),
+//     row 0, row 5 (the K loop is specialised per task: four straight-line bodies); lane = (tile, channel quad); window reads are conflict-free ds_read_b128 (the patch image
+//     keeps a spare pixel after every four columns: a tile's 4-pixel stride becomes 5 pixel slots = 10 bank slots).
+//   patch and V are double-buffered: one workgroup barrier per K step.
+//   epilogue: accumulators -> LDS (one 32-channel half at a time), 256 threads = (tile, channel) pairs run
+//     A^T M A, bias, ReLU (+ 2x2 pool inside the 4x4 tile) and store NHWC.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int W4T = 256;
+
+struct Wino43Args {
+    const float* in; const float* U; const float* bias; float* out;
+    int frames, H, W, Cin, Cout;
+    int nCB;            // Cout / 64
+    int bxN, byN;       // sub-blocks per frame: W/(4 TW), H/(4 TH)
+    int NS;             // workgroups per column block = ceil(NQ / NSUB)
+    int NQ;             // sub-blocks = frames * byN * bxN
+};
+
+// weights: HWIO [3][3][Cin][Cout] -> U_p = G g G^T (float64 arithmetic, stored fp32), packed for the B operand:
+// index = ((((cb * n8 + c8) * 4 + w) * 9 + j) * 2 + nb) * 256 + lane * 4 + q
+//   with plane p = 9 w + j = 6 pi + pj,  c = 8 c8 + 4 (lane >> 5) + q,  cout = 64 cb + 32 nb + (lane & 31)
+__global__ void wino43_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout) {
+    const size_t total = (size_t)36 * Cin * Cout;
+    const int n8 = Cin / 8;
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = idx & 3, lane = (idx >> 2) & 63;
+        size_t r = idx >> 8;
+        const int nb = r & 1; r >>= 1;
+        const int j = (int)(r % 9); r /= 9;
+        const int wv = r & 3; r >>= 2;
+        const int c8 = (int)(r % n8);
+        const int cb = (int)(r / n8);
+        const int p = 9 * wv + j, pi = p / 6, pj = p % 6;
+        const int c = 8 * c8 + 4 * (lane >> 5) + q;
+        const int o = 64 * cb + 32 * nb + (lane & 31);
+        double s = 0.0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) s += G[pi][ky] * G[pj][kx] * (double)w[((size_t)(ky * 3 + kx) * Cin + c) * Cout + o];
+        U[idx] = (float)s;
+    }
+}
+
+template <int N> using ic = std::integral_constant<int, N>;
+
+// B^T of F(4x4,3x3) applied to six values (rows or columns): the pieces the tasks are built from
+__device__ __forceinline__ f32x4 w43_r0(f32x4 d0, f32x4 d2, f32x4 d4) { return 4.f * d0 + (d4 - 5.f * d2); }
+__device__ __forceinline__ f32x4 w43_r5(f32x4 d1, f32x4 d3, f32x4 d5) { return 4.f * d1 + (d5 - 5.f * d3); }
+
+// MFMA with the accumulator in ARCHITECTURAL registers.  The compiler keeps every builtin MFMA's accumulator in the 256
+// accumulation registers; a wave here owns 288, so the ninth plane's two accumulators live in VGPRs and are multiplied
+// through this form (without it the compiler shuttles 32 registers through v_accvgpr_read/write around every use).
+// Hazards: operands come from LDS / global loads (the compiler's waitcnt insertion sees the asm operands); an accumulator
+// is only ever read back by the epilogue, hundreds of instructions after its last MFMA.
+__device__ __forceinline__ void w43_mfma_v(f32x16& c, float av, float bv) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+}
+
+template <bool POOL, int TW, int TH, int NSUB, int PWS, int SPXS>
+__global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino43_kernel(Wino43Args a) {
+    constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 4 * TW + 2, PH = 4 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
+    constexpr int NPXS = NSUB * SPXS;
+    constexpr int NST = (NPX * 2 + W4T - 1) / W4T;                   // float4 staging slots per thread (2 per pixel)
+    constexpr int RAWF = NPXS * 8 + 64;                              // floats per patch buffer (+ scratch for unused slots)
+    constexpr int VF = 36 * 32 * 8;                                  // floats per V buffer
+    constexpr int ZF = 36 * 32 * 32;                                 // epilogue image of one 32-channel half
+    constexpr int LDSF = (2 * RAWF + 2 * VF) > ZF ? (2 * RAWF + 2 * VF) : ZF;
+    static_assert(NTILE == 32, "tile block = 32 MFMA rows");
+    static_assert(LDSF * 4 + 512 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) float s_mem[LDSF];
+    __shared__ int s_sbf[NSUB], s_sby[NSUB], s_sbx[NSUB];
+    float* s_raw = s_mem;                    // [2][RAWF]
+    float* s_V = s_mem + 2 * RAWF;           // [2][VF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    int cb, sp;
+    if (a.nCB >= 8) {
+        const int kN = a.nCB >> 3;
+        cb = (slot % kN) * 8 + xcd;
+        sp = slot / kN;
+    } else {
+        const int per = 8 / a.nCB;
+        cb = xcd % a.nCB;
+        sp = slot * per + xcd / a.nCB;
+    }
+    if (sp >= a.NS) return;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    for (int i = tid; i < (2 * RAWF) / 4; i += W4T) reinterpret_cast<f32x4*>(s_raw)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < NSUB) {
+        const int sq = sp * NSUB + tid;
+        if (sq < a.NQ) {
+            const int bx = sq % a.bxN;
+            const int t1 = sq / a.bxN;
+            s_sbf[tid] = t1 / a.byN; s_sby[tid] = 4 * TH * (t1 % a.byN); s_sbx[tid] = 4 * TW * bx;
+        } else {
+            s_sbf[tid] = -1; s_sby[tid] = 0; s_sbx[tid] = 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- patch staging: NPX pixels x 2 float4 slots per K step.  Addresses are ONE wave-uniform base (advanced by the
+    // scalar unit) + a 32-bit byte offset per slot.  Padding pixels are zeroed once (both buffers are cleared above) and
+    // their slots, like the slots beyond the patch, fetch a valid dummy address and store into a scratch area.
+    const int sq0 = sp * NSUB;
+    const int f0 = (sq0 / a.bxN) / a.byN;                              // first frame this workgroup touches (uniform)
+    const float* pin = a.in + (size_t)f0 * H * W * Cin;
+    unsigned soff[NST];
+    int dst[NST];                                                      // float4 units inside a patch buffer
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int s = tid + k * W4T;
+        const int px = s >> 1, c4 = s & 1;
+        dst[k] = (NPXS * 8) / 4 + (tid & 15);                           // scratch behind the image
+        soff[k] = 0;
+        if (px < NPX) {
+            const int q = px / SPX, lp = px - q * SPX;
+            const int pr = lp / PW, pc = lp - pr * PW;
+            const int fq = s_sbf[q];
+            const int y = s_sby[q] - 1 + pr, x = s_sbx[q] - 1 + pc;
+            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
+                dst[k] = (q * SPXS + pr * PWS + 5 * (pc >> 2) + (pc & 3)) * 2 + c4;
+                soff[k] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + c4 * 4) * sizeof(float));
+            }
+        }
+    }
+    constexpr int NSP = (NST + 2) / 3;                                  // slots per staging piece (three pieces per K step)
+    f32x4 stage[NSP];
+    auto stage_load = [&](const float* base, int g) {
+#pragma unroll
+        for (int k = 0; k < NSP; ++k)
+            if (g * NSP + k < NST) stage[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + soff[g * NSP + k]);
+    };
+    auto stage_store = [&](int buf, int g) {
+        f32x4* rb = reinterpret_cast<f32x4*>(s_raw + buf * RAWF);
+#pragma unroll
+        for (int k = 0; k < NSP; ++k)
+            if (g * NSP + k < NST) rb[dst[g * NSP + k]] = stage[k];
+    };
+
+    // ---- transform lane role: tile = lane >> 1, channel quad = lane & 1
+    const int pt_tile = lane >> 1, pt_c4 = lane & 1;
+    const int pt_q = pt_tile / STILE, pt_tl = pt_tile - pt_q * STILE;
+    const int pt_tr = pt_tl / TW, pt_tc = pt_tl - pt_tr * TW;
+    const int wbase = (pt_q * SPXS + 4 * pt_tr * PWS + 5 * pt_tc) * 8 + pt_c4 * 4;                  // floats
+    const int vwbase = pt_tile * 8 + ((pt_c4 ^ ((pt_tile >> 3) & 1)) * 4);                          // floats, + plane * 256
+    // ---- MFMA lane role
+    const int mrow = lane & 31, kh = lane >> 5;
+    const int vabase = wave * 9 * 256 + mrow * 8 + ((kh ^ ((mrow >> 3) & 1)) * 4);                   // floats, + j * 256
+    const int n8 = Cin / 8;
+
+    f32x16 acc[8][2], accv[2];                 // planes 0..7 (accumulation registers), plane 8 (VGPRs, w43_mfma_v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][nb][r] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[nb][r] = 0.f;
+
+    // ---- K loop, specialised by the wave's transform task (ROLE = wave: 0 plane rows (1,2), 1 rows (3,4), 2 row 0, 3 row 5;
+    // the pairs share their row pass).  The dispatch is hoisted out of the loop: four straight-line loop bodies.
+    const int n8m1 = n8 - 1;
+    const float* ubase = a.U + ((size_t)cb * n8 * 4 + wave) * 4608;   // this wave's 18 KB of K step 0; + c8 * 18432 floats
+    const unsigned ulane = (unsigned)lane * 4u;
+    auto k_loop = [&](auto role_c) {
+        constexpr int ROLE = decltype(role_c)::value;
+        constexpr int NR = ROLE <= 1 ? 4 : 3;                       // window rows the task reads
+        f32x4 D[4], R1[6], R2[6];
+        // window element (aa, b) of this lane's tile: patch row 4 tr + aa, column slot 5 tc + (0,1,2,3,5,6)[b]
+        auto tr_reads = [&](const float* rp, int b) {
+#pragma unroll
+            for (int s = 0; s < NR; ++s) {
+                const int aa = ROLE <= 1 ? 1 + s : (ROLE == 2 ? 2 * s : 1 + 2 * s);
+                D[s] = *reinterpret_cast<const f32x4*>(rp + wbase + (aa * PWS + 5 * (b >> 2) + (b & 3)) * 8);
+            }
+        };
+        auto tr_rows = [&](int b) {
+            if constexpr (ROLE == 0) {                          // rows 1, 2:  (d4 - 4 d2) +- (d3 - 4 d1)
+                const f32x4 t1 = D[3] - 4.f * D[1], t2 = D[2] - 4.f * D[0];
+                R1[b] = t1 + t2; R2[b] = t1 - t2;
+            } else if constexpr (ROLE == 1) {                   // rows 3, 4:  (d4 - d2) +- 2 (d3 - d1)
+                const f32x4 t3 = D[3] - D[1], u = D[2] - D[0];
+                R1[b] = t3 + 2.f * u; R2[b] = t3 - 2.f * u;
+            } else if constexpr (ROLE == 2) {
+                R1[b] = w43_r0(D[0], D[1], D[2]);
+            } else {
+                R1[b] = w43_r5(D[0], D[1], D[2]);
+            }
+        };
+        // column pass of one row-transformed row + store of its six planes (plane row pi)
+        auto tr_cols = [&](float* vb, int pi, const f32x4 (&R)[6]) {
+            float* o = vb + pi * 6 * 256 + vwbase;
+            *reinterpret_cast<f32x4*>(o) = w43_r0(R[0], R[2], R[4]);
+            const f32x4 t1 = R[4] - 4.f * R[2], t2 = R[3] - 4.f * R[1];
+            *reinterpret_cast<f32x4*>(o + 256) = t1 + t2;
+            *reinterpret_cast<f32x4*>(o + 2 * 256) = t1 - t2;
+            const f32x4 t3 = R[4] - R[2], u = R[3] - R[1];
+            *reinterpret_cast<f32x4*>(o + 3 * 256) = t3 + 2.f * u;
+            *reinterpret_cast<f32x4*>(o + 4 * 256) = t3 - 2.f * u;
+            *reinterpret_cast<f32x4*>(o + 5 * 256) = w43_r5(R[1], R[3], R[5]);
+        };
+        auto tr_finish = [&](float* vb) {
+            if constexpr (ROLE == 0) { tr_cols(vb, 1, R1); tr_cols(vb, 2, R2); }
+            else if constexpr (ROLE == 1) { tr_cols(vb, 3, R1); tr_cols(vb, 4, R2); }
+            else if constexpr (ROLE == 2) tr_cols(vb, 0, R1);
+            else tr_cols(vb, 5, R1);
+        };
+
+        // prologue: patches 0 and 1 -> raw[0], raw[1]; patch 0 transformed -> V[0]; U of the first two plane groups requested
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { stage_load(pin, g); stage_store(0, g); }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { stage_load(pin + (n8 > 1 ? 8 : 0), g); stage_store(1, g); }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { tr_reads(s_raw, b); tr_rows(b); }
+        tr_finish(s_V);
+        // B operand: three register sets, one per plane group; group g + 2 (of this or the next K step) is requested when
+        // group g starts: two groups = 3072 MFMA cycles of cover.  A operand: ONE set, re-read for the next group right
+        // after the last MFMA of a group has issued (the transform piece that follows covers the LDS latency).
+        f32x4 Bq[3][3][2], Aq[3];
+        auto load_B = [&](const float* uchunk, int g) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                Bq[g][pl][0] = *reinterpret_cast<const f32x4*>(uchunk + ((3 * g + pl) * 2) * 256 + ulane);
+                Bq[g][pl][1] = *reinterpret_cast<const f32x4*>(uchunk + ((3 * g + pl) * 2 + 1) * 256 + ulane);
+            }
+        };
+        load_B(ubase, 0);
+        load_B(ubase, 1);
+
+        for (int c8 = 0; c8 < n8; ++c8) {
+            const int par = c8 & 1;
+            const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;             // next K step (wraps harmlessly on the last iteration)
+            const int cs = (c8 + 2 < n8) ? c8 + 2 : n8m1;          // K step staged now
+            __syncthreads();                                       // V[par] and raw[par ^ 1] are complete
+            const float* uc = ubase + (size_t)c8 * 18432;
+            const float* un = ubase + (size_t)cn * 18432;
+            const float* pst = pin + cs * 8;
+            const float* vcur = s_V + par * VF + vabase;
+            const float* rnext = s_raw + (par ^ 1) * RAWF;
+            float* vnext = s_V + (par ^ 1) * VF;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + pl * 256);
+            tr_reads(rnext, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                stage_load(pst, g);
+                if (g == 0) load_B(uc, 2); else load_B(un, g - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        if (3 * g + pl < 8) {
+                            acc[3 * g + pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[g][pl][0][q], acc[3 * g + pl][0], 0, 0, 0);
+                            acc[3 * g + pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[g][pl][1][q], acc[3 * g + pl][1], 0, 0, 0);
+                        } else {
+                            w43_mfma_v(accv[0], Aq[pl][q], Bq[g][pl][0][q]);
+                            w43_mfma_v(accv[1], Aq[pl][q], Bq[g][pl][1][q]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                tr_rows(2 * g);
+                tr_reads(rnext, 2 * g + 1);
+                if (g < 2) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + (3 * (g + 1) + pl) * 256);
+                }
+                stage_store(par, g);
+                tr_rows(2 * g + 1);
+                if (g < 2) tr_reads(rnext, 2 * g + 2);
+                else tr_finish(vnext);
+            }
+        }
+    };
+    if (wave == 0) k_loop(ic<0>{});
+    else if (wave == 1) k_loop(ic<1>{});
+    else if (wave == 2) k_loop(ic<2>{});
+    else k_loop(ic<3>{});
+
+    // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
+    float* sZ = s_mem;                                   // [36][32 tiles][32 channels]
+    const int col = lane & 31;
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm-form MFMAs' results are complete before they are read
+#pragma unroll 1
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const f32x16 v = j < 8 ? (nb == 0 ? acc[j][0] : acc[j][1]) : (nb == 0 ? accv[0] : accv[1]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
+                sZ[((9 * wave + j) * 32 + m) * 32 + col] = v[r];
+            }
+        }
+        __syncthreads();
+        const int n = 64 * cb + 32 * nb + col;
+        const float bv = a.bias[n];
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+            const int m = (tid >> 5) + 8 * u;
+            const int mq = m / STILE, ml = m - mq * STILE;
+            const int f = s_sbf[mq];
+            // column part: z[k][j] = sum_i AT[k][i] M[i][j]
+            float z[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float mm[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) mm[i] = sZ[((i * 6 + j) * 32 + m) * 32 + col];
+                const float s12 = mm[1] + mm[2], d12 = mm[1] - mm[2], s34 = mm[3] + mm[4], d34 = mm[3] - mm[4];
+                z[0][j] = mm[0] + s12 + s34;
+                z[1][j] = d12 + 2.f * d34;
+                z[2][j] = s12 + 4.f * s34;
+                z[3][j] = d12 + 8.f * d34 + mm[5];
+            }
+            if (f < 0) continue;
+            float y[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float s12 = z[k][1] + z[k][2], d12 = z[k][1] - z[k][2], s34 = z[k][3] + z[k][4], d34 = z[k][3] - z[k][4];
+                y[k][0] = z[k][0] + s12 + s34;
+                y[k][1] = d12 + 2.f * d34;
+                y[k][2] = s12 + 4.f * s34;
+                y[k][3] = d12 + 8.f * d34 + z[k][5];
+            }
+            const int tr = ml / TW, tc = ml - tr * TW;
+            const int oy = s_sby[mq] + 4 * tr, ox = s_sbx[mq] + 4 * tc;
+            if constexpr (POOL) {
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float v = fmaxf(fmaxf(y[2 * aa][2 * b], y[2 * aa][2 * b + 1]), fmaxf(y[2 * aa + 1][2 * b], y[2 * aa + 1][2 * b + 1]));
+                        a.out[(((size_t)f * (H >> 1) + (oy >> 1) + aa) * (W >> 1) + (ox >> 1) + b) * Cout + n] = fmaxf(v + bv, 0.f);
+                    }
+            } else {
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        a.out[(((size_t)f * H + oy + aa) * W + ox + b) * Cout + n] = fmaxf(y[aa][b] + bv, 0.f);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ntk_vgg_wino43_packed_floats(int cin, int cout) { return (size_t)36 * cin * cout; }
+
+extern "C" int ntk_vgg_pack_weights_wino43(const float* w_hwio, float* u_packed, int cin, int cout, void* stream) {
+    NTK_REQUIRE(w_hwio && u_packed, NTK_ERR_BAD_PTR, "ntk_vgg_pack_weights_wino43: null pointer");
+    NTK_REQUIRE(cin >= 16 && (cin % 16) == 0 && cout >= 64 && (cout % 64) == 0, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_pack_weights_wino43: cin=%d (multiple of 16) cout=%d (multiple of 64)", cin, cout);
+    wino43_pack_kernel<<<2048, 256, 0, (hipStream_t)stream>>>(w_hwio, u_packed, cin, cout);
+    NTK_CHECK_LAUNCH("ntk_vgg_pack_weights_wino43");
+    return NTK_OK;
+}
+
+extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                               int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream) {
+    NTK_REQUIRE(in && u_packed && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_wino43_f32: null pointer");
+    NTK_REQUIRE(ntk_aligned16(in) && ntk_aligned16(u_packed) && ntk_aligned16(out), NTK_ERR_BAD_PTR,
+                "ntk_vgg_conv3x3_relu_wino43_f32: 16-byte alignment");
+    NTK_REQUIRE(frames > 0 && H >= 4 && (H % 4) == 0 && W >= 4 && (W % 4) == 0, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino43_f32: frames=%d H=%d W=%d (H, W multiples of 4)", frames, H, W);
+    NTK_REQUIRE(cin >= 16 && (cin % 16) == 0 && cout >= 64 && (cout % 64) == 0, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino43_f32: cin=%d (multiple of 16: the K loop takes two 8-channel steps per trip) "
+                "cout=%d (multiple of 64)", cin, cout);
+    NTK_REQUIRE((unsigned long long)2 * H * W * cin * sizeof(float) < 0xffffffffull, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino43_f32: two frames of %d x %d x %d floats exceed the 32-bit staging offsets", H, W, cin);
+    Wino43Args a;
+    a.in = in; a.U = u_packed; a.bias = bias; a.out = out;
+    a.frames = frames; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
+    // tile-block shape: 0 = 8x4x1 (tile grid multiple of 8 x 4), 1 = 4x4x2, 2 = 2x2x8, 3 = 1x1x32 (any grid)
+    const int gw = W / 4, gh = H / 4;
+    const int shape = ((gw % 8) == 0 && (gh % 4) == 0) ? 0 : (((gw % 4) == 0 && (gh % 4) == 0) ? 1 : (((gw % 2) == 0 && (gh % 2) == 0) ? 2 : 3));
+    static const int TWs[4] = {8, 4, 2, 1}, THs[4] = {4, 4, 2, 1}, NSUBs[4] = {1, 2, 8, 32};
+    a.nCB = cout / 64;
+    a.bxN = gw / TWs[shape];
+    a.byN = gh / THs[shape];
+    const long long NQ = (long long)frames * a.byN * a.bxN;
+    const long long NS = (NQ + NSUBs[shape] - 1) / NSUBs[shape];
+    NTK_REQUIRE(NS < (1ll << 30) && (a.nCB <= 8 ? (8 % a.nCB) == 0 : (a.nCB % 8) == 0), NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino43_f32: cout/64=%d must divide or be a multiple of 8", a.nCB);
+    a.NS = (int)NS;
+    a.NQ = (int)NQ;
+    long long slots;
+    if (a.nCB >= 8) slots = NS * (a.nCB / 8);
+    else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
+    const long long grid = slots * 8;
+    NTK_REQUIRE(grid < (1ll << 31), NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino43_f32: grid too large");
+#define W43_LAUNCH(POOL_, TW_, TH_, NSUB_, PWS_, SPXS_) \
+    conv3x3_wino43_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4T, 0, (hipStream_t)stream>>>(a)
+    // PWS / SPXS: pixel-slot strides of a patch row / a sub-block, chosen so that the sixteen lanes of every window
+    // ds_read_b128 fall on sixteen different 16-byte bank slots (tile stride 10 slots; row / sub-block strides = 8 / 6 mod 16)
+    if (shape == 0) { if (fuse_pool) W43_LAUNCH(true, 8, 4, 1, 42, 18 * 42); else W43_LAUNCH(false, 8, 4, 1, 42, 18 * 42); }
+    else if (shape == 1) { if (fuse_pool) W43_LAUNCH(true, 4, 4, 2, 23, 18 * 23); else W43_LAUNCH(false, 4, 4, 2, 23, 18 * 23); }
+    else if (shape == 2) { if (fuse_pool) W43_LAUNCH(true, 2, 2, 8, 13, 10 * 13); else W43_LAUNCH(false, 2, 2, 8, 13, 10 * 13); }
+    else { if (fuse_pool) W43_LAUNCH(true, 1, 1, 32, 7, 43); else W43_LAUNCH(false, 1, 1, 32, 7, 43); }
+#undef W43_LAUNCH
+    NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_wino43_f32");
+    return NTK_OK;
+}

@@ -90,6 +90,38 @@ def conv3x3_relu_wino(x, u_packed, bias, cin, cout, fuse_pool=False, out=None):
     return out
 
 
+def wino43_supported(cin, cout, H, W, frames=1):
+    """Shapes the fused Winograd F(4x4,3x3) kernel takes."""
+    nCB = cout // 64
+    return (cin % 16 == 0 and cout % 64 == 0 and nCB >= 1 and (8 % nCB == 0 if nCB <= 8 else nCB % 8 == 0)
+            and H % 4 == 0 and W % 4 == 0 and 2 * H * W * cin * 4 < 0xffffffff)
+
+
+def pack_weights_wino43(w_hwio):
+    """[3,3,Cin,Cout] (TF HWIO) -> the 36 Winograd-domain planes U = G g G^T of F(4x4,3x3), packed for the MFMA B operand."""
+    kh, kw, cin, cout = w_hwio.shape
+    assert kh == 3 and kw == 3
+    L = _lib.lib()
+    u = torch.empty(L.ntk_vgg_wino43_packed_floats(cin, cout), device=w_hwio.device, dtype=torch.float32)
+    w = w_hwio.contiguous()
+    _lib.check(L.ntk_vgg_pack_weights_wino43(_lib.ptr(w), _lib.ptr(u), cin, cout, _lib.stream()), "ntk_vgg_pack_weights_wino43")
+    return u
+
+
+def conv3x3_relu_wino43(x, u_packed, bias, cin, cout, fuse_pool=False, out=None):
+    """Same operator as conv3x3_relu by fused Winograd F(4x4,3x3) (csrc/conv_wino43.hip)."""
+    F, H, W, C = x.shape
+    if C != cin:
+        raise _lib.NtkError("conv3x3_relu_wino43: input has %d channels, layer expects %d" % (C, cin))
+    oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
+    if out is None:
+        out = torch.empty((F, oh, ow, cout), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_wino43_f32(_lib.ptr(x), _lib.ptr(u_packed), _lib.ptr(bias), _lib.ptr(out),
+                                                          F, H, W, cin, cout, 1 if fuse_pool else 0, _lib.stream()),
+               "ntk_vgg_conv3x3_relu_wino43_f32")
+    return out
+
+
 def conv3x3_relu_bf16(x, w_packed, bias, cin, cout, fuse_pool=False, out_f32=False, out=None):
     """bf16 NHWC activations [F,H,W,Cin] -> relu(conv3x3_same(x)+b) in bf16 (or fp32 when out_f32)."""
     F, H, W, C = x.shape
