@@ -28,7 +28,12 @@ import torch
 # counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv
 # (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
-TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd": 8.3752e10 + 2.3121e10}
+TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": None}
+TRUNK_TRAFFIC_PROFILE = {"direct": "profiles/r01_vgg_trunk_hbm_traffic_pmc.csv", "winograd2": "profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv",
+                         "winograd": "profiles/r02_vgg_trunk_wino43_hbm_traffic_pmc.csv"}
+# fraction of the direct-convolution multiplies the Winograd layers execute on the MFMA pipe: F(2x2,3x3) 16 per 2x2 tile
+# where the direct form has 36; F(4x4,3x3) 36 per 4x4 tile where it has 144
+WINO_EXECUTED_FRACTION = {"winograd": 36.0 / 144.0, "winograd2": 16.0 / 36.0}
 NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.451e8 + 1.036e9     # profiles/r01_ntm_seq_hbm_traffic_pmc.csv
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
@@ -220,7 +225,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--model", default="ntm", choices=["ntm", "dnc"],
                     help="ntm = BASELINE configs[1] (the headline metric); dnc = configs[2] (DNC 256x64, 4 read heads), reported for reference")
-    ap.add_argument("--conv-algo", default="winograd", choices=["winograd", "direct"],
+    ap.add_argument("--conv-algo", default="winograd", choices=["winograd", "winograd2", "direct"],
                     help="fp32 trunk: fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (default) or the direct implicit-GEMM kernel")
     ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact fp32 MFMA (configs 2-4, the headline); bf16 = bf16 operands / fp32 accumulate (config 5)")
@@ -338,11 +343,11 @@ def main():
         ntm_ms = float(np.mean([a.elapsed_time(b) for a, b in marks_ntm])) if marks_ntm else 0.0
         flops = conv_flops_per_frame() * B * T
         algorithmic = flops / (vgg_ms * 1e-3) / 1e12
-        # executed MFMA flops: conv1_1 runs the direct kernel; the nine Winograd F(2x2,3x3) layers execute 16 multiplies
-        # per 2x2 output tile and channel pair where the direct form has 36 (x 4/9)
+        # executed MFMA flops: conv1_1 runs the direct kernel; the nine Winograd layers execute a fixed fraction of the
+        # direct form's multiplies (WINO_EXECUTED_FRACTION)
         c11 = 2 * 224 * 224 * 9 * 3 * 64 * B * T
-        wino = args.conv_algo == "winograd" and args.conv_dtype == "f32"
-        executed_flops = (c11 + (flops - c11) * 4.0 / 9.0) if wino else flops
+        wino = args.conv_algo in WINO_EXECUTED_FRACTION and args.conv_dtype == "f32"
+        executed_flops = (c11 + (flops - c11) * WINO_EXECUTED_FRACTION[args.conv_algo]) if wino else flops
         achieved = executed_flops / (vgg_ms * 1e-3) / 1e12
         PEAK = FP32_MFMA_PEAK_TFLOPS if args.conv_dtype == "f32" else 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
         out = {
@@ -362,20 +367,23 @@ def main():
                                     % (4 if trk.core.N >= 512 else 2, trk.core.N, trk.core.W, "training" if args.mode == "train" else "inference", B, T)),
                        "global_batch": world * B, "seq_len": T, "steps_per_sequence": T * 65,
                        "parallelism": "dp%d" % world, "mode": args.mode},
-            "roofline": {"bound": "mfma", "kernel": (("conv3x3_wino_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(2x2,3x3) layers)"
-                                                      if args.conv_algo == "winograd" else "conv3x3_relu_dma_kernel (VGG trunk, 10 layers)")
+            "roofline": {"bound": "mfma", "kernel": (("conv3x3_wino43_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(4x4,3x3) layers)"
+                                                      if args.conv_algo == "winograd" else
+                                                      ("conv3x3_wino_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(2x2,3x3) layers)"
+                                                       if args.conv_algo == "winograd2" else "conv3x3_relu_dma_kernel (VGG trunk, 10 layers)"))
                                                      if args.conv_dtype == "f32" else "conv3x3_relu_bf16_kernel (VGG trunk, 10 layers)"),
                          "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4),
                          "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo] * (B * T) / 640.0)
                          if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo]) else None,
-                         "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv; direct kernels: r01_vgg_trunk_hbm_traffic_pmc.csv), scaled by frames/640; algorithmic 4.563e10 B per 640 frames",
+                         "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (%s), scaled by frames/640; algorithmic 4.563e10 B per 640 frames" % TRUNK_TRAFFIC_PROFILE[args.conv_algo],
                          "algorithmic_flops_per_frame": conv_flops_per_frame(),
                          "executed_flops_per_frame": executed_flops / (B * T),
                          "algorithmic_tflops": round(algorithmic, 2),
-                         "note": ("achieved / frac = EXECUTED MFMA flops (conv1_1 direct + 4/9 of the direct-convolution count for the "
+                         "note": ("achieved / frac = EXECUTED MFMA flops (conv1_1 direct + %.4f of the direct-convolution count for the "
                                   "nine Winograd layers) / trunk time measured with HIP events on the trunk's stream inside the timed "
                                   "region; algorithmic_tflops = the direct-convolution count (SURVEY 8d: 27.92 GFLOP/frame) / the same time")
+                                 % WINO_EXECUTED_FRACTION[args.conv_algo]
                                  if wino else "direct convolution: executed = algorithmic flops"},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},

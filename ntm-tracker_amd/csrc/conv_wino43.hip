@@ -25,6 +25,32 @@
 #include "common.h"
 #include <type_traits>
 
+// Diagnostic build only (make prof, -DNTK_CL_PROF): lane 0 of every wave of ONE workgroup accumulates s_memtime deltas per
+// section of the K loop into g_w43_prof[wave][section]; ntk_vgg_wino43_prof() copies them out (read SHARES, not totals).
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_w43_prof[4][24];
+#define W43_STAMP(i)                                                                  \
+    do {                                                                              \
+        if (prof_on) {                                                                \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+            prof_acc[i] += now_ - prof_last;                                          \
+            prof_last = now_;                                                         \
+        }                                                                             \
+    } while (0)
+#else
+#define W43_STAMP(i) do { } while (0)
+#endif
+
+// Ablation switches for scripts/dev_wino_variant.sh (results are WRONG with any of them set; never defined in the product
+// build): bit 0 no U loads in the K loop, bit 1 no input transform, bit 2 no patch staging, bit 3 no workgroup barrier in
+// the K loop, bit 4 no A-operand reads.
+#ifndef W43_ABL
+#define W43_ABL 0
+#endif
+#ifndef W43_STAGE_AUX
+#define W43_STAGE_AUX 0      // cache-policy bits of the patch loads (2 = non-temporal: measured)
+#endif
+
 namespace {
 
 constexpr int W4T = 256;
@@ -110,7 +136,6 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (sp >= a.NS) return;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-    for (int i = tid; i < (2 * RAWF) / 4; i += W4T) reinterpret_cast<f32x4*>(s_raw)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < NSUB) {
         const int sq = sp * NSUB + tid;
         if (sq < a.NQ) {
@@ -123,12 +148,16 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
 
-    // ---- patch staging: NPX pixels x 2 float4 slots per K step.  Addresses are ONE wave-uniform base (advanced by the
-    // scalar unit) + a 32-bit byte offset per slot.  Padding pixels are zeroed once (both buffers are cleared above) and
-    // their slots, like the slots beyond the patch, fetch a valid dummy address and store into a scratch area.
+    // ---- patch staging: NPX pixels x 2 float4 slots per K step through raw buffer loads: ONE resource per K step (its base
+    // advanced by the scalar unit) + a 32-bit byte offset per slot: no vector address arithmetic in the loop.  Padding
+    // pixels carry an out-of-range offset: the buffer unit returns zeros for them.  Slots beyond the patch store into a
+    // scratch area behind the image.
     const int sq0 = sp * NSUB;
     const int f0 = (sq0 / a.bxN) / a.byN;                              // first frame this workgroup touches (uniform)
     const float* pin = a.in + (size_t)f0 * H * W * Cin;
+    const size_t in_left = ((size_t)(a.frames - f0) * H * W * Cin) * sizeof(float);
+    const unsigned in_bytes = (unsigned)(in_left < 0x40000000ull ? in_left : 0x40000000ull);
+    constexpr unsigned W43_OOB = 0x7ffffff0u;
     unsigned soff[NST];
     int dst[NST];                                                      // float4 units inside a patch buffer
 #pragma unroll
@@ -136,30 +165,27 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int s = tid + k * W4T;
         const int px = s >> 1, c4 = s & 1;
         dst[k] = (NPXS * 8) / 4 + (tid & 15);                           // scratch behind the image
-        soff[k] = 0;
+        soff[k] = W43_OOB;
         if (px < NPX) {
             const int q = px / SPX, lp = px - q * SPX;
             const int pr = lp / PW, pc = lp - pr * PW;
             const int fq = s_sbf[q];
             const int y = s_sby[q] - 1 + pr, x = s_sbx[q] - 1 + pc;
-            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W) {
-                dst[k] = (q * SPXS + pr * PWS + 5 * (pc >> 2) + (pc & 3)) * 2 + c4;
+            dst[k] = (q * SPXS + pr * PWS + 5 * (pc >> 2) + (pc & 3)) * 2 + c4;
+            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W)
                 soff[k] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + c4 * 4) * sizeof(float));
-            }
         }
     }
-    constexpr int NSP = (NST + 2) / 3;                                  // slots per staging piece (three pieces per K step)
-    f32x4 stage[NSP];
-    auto stage_load = [&](const float* base, int g) {
+    f32x4 stage[NST];
+    auto stage_load = [&](int cs) {                                    // K step cs: channels 8 cs .. 8 cs + 7
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + cs * 8), 0, (int)(in_bytes - cs * 32), 0x00020000);
 #pragma unroll
-        for (int k = 0; k < NSP; ++k)
-            if (g * NSP + k < NST) stage[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + soff[g * NSP + k]);
+        for (int k = 0; k < NST; ++k) stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, soff[k], 0, W43_STAGE_AUX));
     };
-    auto stage_store = [&](int buf, int g) {
+    auto stage_store = [&](int buf) {
         f32x4* rb = reinterpret_cast<f32x4*>(s_raw + buf * RAWF);
 #pragma unroll
-        for (int k = 0; k < NSP; ++k)
-            if (g * NSP + k < NST) rb[dst[g * NSP + k]] = stage[k];
+        for (int k = 0; k < NST; ++k) rb[dst[k]] = stage[k];
     };
 
     // ---- transform lane role: tile = lane >> 1, channel quad = lane & 1
@@ -188,8 +214,10 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- K loop, specialised by the wave's transform task (ROLE = wave: 0 plane rows (1,2), 1 rows (3,4), 2 row 0, 3 row 5;
     // the pairs share their row pass).  The dispatch is hoisted out of the loop: four straight-line loop bodies.
     const int n8m1 = n8 - 1;
-    const float* ubase = a.U + ((size_t)cb * n8 * 4 + wave) * 4608;   // this wave's 18 KB of K step 0; + c8 * 18432 floats
-    const unsigned ulane = (unsigned)lane * 4u;
+#ifdef NTK_CL_PROF
+    const bool prof_on = blockIdx.x == 1000 && lane == 0;
+    unsigned long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = __builtin_amdgcn_s_memtime();
+#endif
     auto k_loop = [&](auto role_c) {
         constexpr int ROLE = decltype(role_c)::value;
         constexpr int NR = ROLE <= 1 ? 4 : 3;                       // window rows the task reads
@@ -234,72 +262,99 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             else tr_cols(vb, 5, R1);
         };
 
-        // prologue: patches 0 and 1 -> raw[0], raw[1]; patch 0 transformed -> V[0]; U of the first two plane groups requested
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { stage_load(pin, g); stage_store(0, g); }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { stage_load(pin + (n8 > 1 ? 8 : 0), g); stage_store(1, g); }
+        // prologue: patches 0 and 1 -> raw[0], raw[1]; patch 0 transformed -> V[0]; U of the first plane group requested
+        W43_STAMP(16);
+        stage_load(0); stage_store(0);
+        stage_load(n8 > 1 ? 1 : 0); stage_store(1);
         __syncthreads();
+        W43_STAMP(17);
 #pragma unroll
         for (int b = 0; b < 6; ++b) { tr_reads(s_raw, b); tr_rows(b); }
         tr_finish(s_V);
-        // B operand: three register sets, one per plane group; group g + 2 (of this or the next K step) is requested when
-        // group g starts: two groups = 3072 MFMA cycles of cover.  A operand: ONE set, re-read for the next group right
-        // after the last MFMA of a group has issued (the transform piece that follows covers the LDS latency).
-        f32x4 Bq[3][3][2], Aq[3];
-        auto load_B = [&](const float* uchunk, int g) {
+        // B operand: two register sets alternating by plane-group parity (the K loop is unrolled by two so that the parity is
+        // static); group G + 1 is requested when group G starts.  vmcnt retires in order, so the request order matters: the
+        // U request precedes the K step's patch requests (HBM latency), which then only have to be back two groups later,
+        // when they are stored.  A operand: ONE set, re-read for the next group right after a group's last MFMA has issued.
+        f32x4 Bq[2][3][2], Aq[3];
+        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.U + ((size_t)cb * n8 * 4 + wave) * 4608), 0, (int)((size_t)n8 * 18432 * sizeof(float) - (size_t)wave * 4608 * sizeof(float)), 0x00020000);
+        const unsigned ulane = (unsigned)lane * 16u;                     // bytes
+        auto load_B = [&](int c, int g, int set) {                        // K step c, plane group g
+            const int sbase = c * 73728 + g * 6144;                       // bytes: 18432 floats per K step, 3 planes x 2 x 256 per group
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                Bq[g][pl][0] = *reinterpret_cast<const f32x4*>(uchunk + ((3 * g + pl) * 2) * 256 + ulane);
-                Bq[g][pl][1] = *reinterpret_cast<const f32x4*>(uchunk + ((3 * g + pl) * 2 + 1) * 256 + ulane);
+                Bq[set][pl][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane + (pl * 2) * 1024, sbase, 0));
+                Bq[set][pl][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane + (pl * 2 + 1) * 1024, sbase, 0));
             }
         };
-        load_B(ubase, 0);
-        load_B(ubase, 1);
+        load_B(0, 0, 0);
+        W43_STAMP(18);
 
-        for (int c8 = 0; c8 < n8; ++c8) {
-            const int par = c8 & 1;
+        auto k_step = [&](int c8, auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;            // c8 & 1
             const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;             // next K step (wraps harmlessly on the last iteration)
             const int cs = (c8 + 2 < n8) ? c8 + 2 : n8m1;          // K step staged now
-            __syncthreads();                                       // V[par] and raw[par ^ 1] are complete
-            const float* uc = ubase + (size_t)c8 * 18432;
-            const float* un = ubase + (size_t)cn * 18432;
-            const float* pst = pin + cs * 8;
-            const float* vcur = s_V + par * VF + vabase;
-            const float* rnext = s_raw + (par ^ 1) * RAWF;
-            float* vnext = s_V + (par ^ 1) * VF;
+            W43_STAMP(15);
+            if constexpr (!(W43_ABL & 8)) __syncthreads();         // V[PAR] and raw[PAR ^ 1] are complete
+            W43_STAMP(0);
+            const float* vcur = s_V + PAR * VF + vabase;
+            const float* rnext = s_raw + (PAR ^ 1) * RAWF;
+            float* vnext = s_V + (PAR ^ 1) * VF;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + pl * 256);
-            tr_reads(rnext, 0);
+            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + pl * 256);
+            if constexpr (!(W43_ABL & 2)) tr_reads(rnext, 0);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                stage_load(pst, g);
-                if (g == 0) load_B(uc, 2); else load_B(un, g - 1);
-                __builtin_amdgcn_sched_barrier(0);
+                const int bs = (PAR + g) & 1;
+                if constexpr (!(W43_ABL & 1)) { if (g < 2) load_B(c8, g + 1, bs ^ 1); else load_B(cn, 0, bs ^ 1); }
+                if constexpr (!(W43_ABL & 4)) if (g == 0) stage_load(cs);
+                W43_STAMP(1);
+                // a plane group's 24 MFMAs in two halves (K pairs 0-1, 2-3) with one of the gap's two transform columns
+                // after each: the window reads of a column get 12 MFMAs (768 cycles) of cover -- with one wave per SIMD a
+                // wait is an idle SIMD
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int half = 0; half < 2; ++half) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        if (3 * g + pl < 8) {
-                            acc[3 * g + pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[g][pl][0][q], acc[3 * g + pl][0], 0, 0, 0);
-                            acc[3 * g + pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[g][pl][1][q], acc[3 * g + pl][1], 0, 0, 0);
-                        } else {
-                            w43_mfma_v(accv[0], Aq[pl][q], Bq[g][pl][0][q]);
-                            w43_mfma_v(accv[1], Aq[pl][q], Bq[g][pl][1][q]);
+                    for (int q = 2 * half; q < 2 * half + 2; ++q)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            if (3 * g + pl < 8) {
+                                acc[3 * g + pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[bs][pl][0][q], acc[3 * g + pl][0], 0, 0, 0);
+                                acc[3 * g + pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[bs][pl][1][q], acc[3 * g + pl][1], 0, 0, 0);
+                            } else {
+                                w43_mfma_v(accv[0], Aq[pl][q], Bq[bs][pl][0][q]);
+                                w43_mfma_v(accv[1], Aq[pl][q], Bq[bs][pl][1][q]);
+                            }
                         }
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-                tr_rows(2 * g);
-                tr_reads(rnext, 2 * g + 1);
-                if (g < 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    W43_STAMP(2 + 4 * g + 2 * half);
+                    if (half == 0) {
+                        if constexpr (!(W43_ABL & 2)) {
+                            tr_rows(2 * g);
+                            tr_reads(rnext, 2 * g + 1);
+                        }
+                        W43_STAMP(3 + 4 * g);
+                    } else {
+                        if (g < 2) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + (3 * (g + 1) + pl) * 256);
+                            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + (3 * (g + 1) + pl) * 256);
+                        } else {
+                            if constexpr (!(W43_ABL & 4)) stage_store(PAR);
+                        }
+                        if constexpr (!(W43_ABL & 2)) {
+                            tr_rows(2 * g + 1);
+                            if (g < 2) tr_reads(rnext, 2 * g + 2);
+                            else tr_finish(vnext);
+                        }
+                        W43_STAMP(5 + 4 * g);
+                    }
                 }
-                stage_store(par, g);
-                tr_rows(2 * g + 1);
-                if (g < 2) tr_reads(rnext, 2 * g + 2);
-                else tr_finish(vnext);
             }
+        };
+        for (int c8 = 0; c8 < n8; c8 += 2) {
+            k_step(c8, ic<0>{});
+            k_step(c8 + 1, ic<1>{});
         }
     };
     if (wave == 0) k_loop(ic<0>{});
@@ -307,6 +362,9 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else if (wave == 2) k_loop(ic<2>{});
     else k_loop(ic<3>{});
 
+#ifdef NTK_CL_PROF
+    W43_STAMP(15);
+#endif
     // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
     float* sZ = s_mem;                                   // [36][32 tiles][32 channels]
     const int col = lane & 31;
@@ -314,6 +372,7 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll 1
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();
+        W43_STAMP(19);
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const f32x16 v = j < 8 ? (nb == 0 ? acc[j][0] : acc[j][1]) : (nb == 0 ? accv[0] : accv[1]);
@@ -323,7 +382,9 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 sZ[((9 * wave + j) * 32 + m) * 32 + col] = v[r];
             }
         }
+        W43_STAMP(20);
         __syncthreads();
+        W43_STAMP(21);
         const int n = 64 * cb + 32 * nb + col;
         const float bv = a.bias[n];
 #pragma unroll 1
@@ -372,10 +433,21 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         a.out[(((size_t)f * H + oy + aa) * W + ox + b) * Cout + n] = fmaxf(y[aa][b] + bv, 0.f);
             }
         }
+        W43_STAMP(22);
     }
+#ifdef NTK_CL_PROF
+    if (prof_on)
+        for (int i = 0; i < 24; ++i) g_w43_prof[wave][i] = prof_acc[i];
+#endif
 }
 
 }  // namespace
+
+#ifdef NTK_CL_PROF
+extern "C" int ntk_vgg_wino43_prof(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_w43_prof), 96 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#endif
 
 extern "C" size_t ntk_vgg_wino43_packed_floats(int cin, int cout) { return (size_t)36 * cin * cout; }
 

@@ -157,14 +157,17 @@ class VGG16Conv43(object):
         self.chunk_frames = int(chunk_frames)
         if dtype not in ("f32", "bf16"):
             raise _lib.NtkError("VGG16Conv43: dtype must be 'f32' or 'bf16'")
-        if algo not in ("winograd", "direct"):
-            raise _lib.NtkError("VGG16Conv43: algo must be 'winograd' or 'direct'")
+        if algo not in ("winograd", "winograd2", "direct"):
+            raise _lib.NtkError("VGG16Conv43: algo must be 'winograd', 'winograd2' or 'direct'")
         self.dtype = dtype
-        # fp32 trunk: fused Winograd F(2x2,3x3) wherever the layer shape allows (conv1_2 .. conv4_3 on 224x224 frames),
-        # the direct implicit-GEMM kernel otherwise (conv1_1, odd frame sizes); "direct" forces the latter everywhere
+        # fp32 trunk: "winograd" = fused Winograd F(4x4,3x3) wherever the layer shape allows (conv1_2 .. conv4_3 on
+        # 224x224 frames; 4x fewer multiplies than the direct form, error ~1e-5 of the activation scale per layer),
+        # "winograd2" = fused Winograd F(2x2,3x3) (2.25x fewer multiplies, error ~3e-7 per layer); the direct
+        # implicit-GEMM kernel runs where neither applies (conv1_1, odd frame sizes) and everywhere with "direct"
         self.algo = algo
         self.packed = {}
         self.packed_wino = {}
+        self.packed_wino43 = {}
         for name, cin, cout, _pool in VGG_LAYERS:
             w, b = weights[name]
             w = torch.as_tensor(w, dtype=torch.float32).to(self.device)
@@ -175,8 +178,10 @@ class VGG16Conv43(object):
                 self.packed[name] = (pack_weights_bf16(w), b)
             else:
                 self.packed[name] = (pack_weights(w), b)
-                if dtype == "f32" and algo == "winograd" and cin % 16 == 0:
+                if dtype == "f32" and algo in ("winograd", "winograd2") and cin % 16 == 0:
                     self.packed_wino[name] = pack_weights_wino(w)
+                    if algo == "winograd":
+                        self.packed_wino43[name] = pack_weights_wino43(w)
 
     def _forward_chunk_bf16(self, frames, out=None):
         F, H, W, _ = frames.shape
@@ -200,7 +205,10 @@ class VGG16Conv43(object):
         for name, cin, cout, pool in VGG_LAYERS:
             wp, b = self.packed[name]
             last = (name == upto)
-            if name in self.packed_wino and wino_supported(cin, cout, x.shape[1], x.shape[2], x.shape[0]):
+            if name in self.packed_wino43 and wino43_supported(cin, cout, x.shape[1], x.shape[2], x.shape[0]):
+                x = conv3x3_relu_wino43(x, self.packed_wino43[name], b, cin, cout, fuse_pool=(pool and not last),
+                                        out=out if last else None)
+            elif name in self.packed_wino and wino_supported(cin, cout, x.shape[1], x.shape[2], x.shape[0]):
                 x = conv3x3_relu_wino(x, self.packed_wino[name], b, cin, cout, fuse_pool=(pool and not last),
                                       out=out if last else None)
             else:
