@@ -20,8 +20,8 @@
 //     row 0, row 5 (the K loop is specialised per task: four straight-line bodies); lane = (tile, channel quad); window reads are conflict-free ds_read_b128 (the patch image
 //     keeps a spare pixel after every four columns: a tile's 4-pixel stride becomes 5 pixel slots = 10 bank slots).
 //   patch and V are double-buffered: one workgroup barrier per K step.
-//   epilogue: accumulators -> LDS (one 32-channel half at a time), 256 threads = (tile, channel) pairs run
-//     A^T M A, bias, ReLU (+ 2x2 pool inside the 4x4 tile) and store NHWC.
+//   epilogue: accumulators -> LDS (one 32-channel half at a time), 256 threads = (tile, four adjacent channels) run
+//     A^T M A, bias, ReLU (+ 2x2 pool inside the 4x4 tile) and store one float4 per pixel, NHWC.
 #include "common.h"
 #include <type_traits>
 
@@ -264,8 +264,19 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         // prologue: patches 0 and 1 -> raw[0], raw[1]; patch 0 transformed -> V[0]; U of the first plane group requested
         W43_STAMP(16);
-        stage_load(0); stage_store(0);
-        stage_load(n8 > 1 ? 1 : 0); stage_store(1);
+        {
+            // both patches are requested before either is stored: one HBM round trip, not two
+            f32x4 stage1[NST];
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + (n8 > 1 ? 8 : 0)), 0,
+                                                                                   (int)(in_bytes - (n8 > 1 ? 32 : 0)), 0x00020000);
+            stage_load(0);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) stage1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, soff[k], 0, W43_STAGE_AUX));
+            stage_store(0);
+            f32x4* rb1 = reinterpret_cast<f32x4*>(s_raw + RAWF);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) rb1[dst[k]] = stage1[k];
+        }
         __syncthreads();
         W43_STAMP(17);
 #pragma unroll
@@ -385,31 +396,31 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W43_STAMP(20);
         __syncthreads();
         W43_STAMP(21);
-        const int n = 64 * cb + 32 * nb + col;
-        const float bv = a.bias[n];
-#pragma unroll 1
-        for (int u = 0; u < 4; ++u) {
-            const int m = (tid >> 5) + 8 * u;
-            const int mq = m / STILE, ml = m - mq * STILE;
-            const int f = s_sbf[mq];
+        // thread = (tile m, four adjacent output channels): 36 conflict-free ds_read_b128, one float4 store per pixel
+        const int m = tid >> 3, cq = tid & 7;
+        const int n = 64 * cb + 32 * nb + 4 * cq;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+        const int mq = m / STILE, ml = m - mq * STILE;
+        const int f = s_sbf[mq];
+        if (f >= 0) {
+            const f32x4* zp = reinterpret_cast<const f32x4*>(sZ + m * 32 + 4 * cq);      // + plane * 256 float4
             // column part: z[k][j] = sum_i AT[k][i] M[i][j]
-            float z[4][6];
+            f32x4 z[4][6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                float mm[6];
+                f32x4 mm[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) mm[i] = sZ[((i * 6 + j) * 32 + m) * 32 + col];
-                const float s12 = mm[1] + mm[2], d12 = mm[1] - mm[2], s34 = mm[3] + mm[4], d34 = mm[3] - mm[4];
+                for (int i = 0; i < 6; ++i) mm[i] = zp[(i * 6 + j) * 256];
+                const f32x4 s12 = mm[1] + mm[2], d12 = mm[1] - mm[2], s34 = mm[3] + mm[4], d34 = mm[3] - mm[4];
                 z[0][j] = mm[0] + s12 + s34;
                 z[1][j] = d12 + 2.f * d34;
                 z[2][j] = s12 + 4.f * s34;
                 z[3][j] = d12 + 8.f * d34 + mm[5];
             }
-            if (f < 0) continue;
-            float y[4][4];
+            f32x4 y[4][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float s12 = z[k][1] + z[k][2], d12 = z[k][1] - z[k][2], s34 = z[k][3] + z[k][4], d34 = z[k][3] - z[k][4];
+                const f32x4 s12 = z[k][1] + z[k][2], d12 = z[k][1] - z[k][2], s34 = z[k][3] + z[k][4], d34 = z[k][3] - z[k][4];
                 y[k][0] = z[k][0] + s12 + s34;
                 y[k][1] = d12 + 2.f * d34;
                 y[k][2] = s12 + 4.f * s34;
@@ -417,20 +428,33 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             const int tr = ml / TW, tc = ml - tr * TW;
             const int oy = s_sby[mq] + 4 * tr, ox = s_sbx[mq] + 4 * tc;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             if constexpr (POOL) {
+                float* op = a.out + (((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n;
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const float v = fmaxf(fmaxf(y[2 * aa][2 * b], y[2 * aa][2 * b + 1]), fmaxf(y[2 * aa + 1][2 * b], y[2 * aa + 1][2 * b + 1]));
-                        a.out[(((size_t)f * (H >> 1) + (oy >> 1) + aa) * (W >> 1) + (ox >> 1) + b) * Cout + n] = fmaxf(v + bv, 0.f);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = fmaxf(fmaxf(y[2 * aa][2 * b][e], y[2 * aa][2 * b + 1][e]), fmaxf(y[2 * aa + 1][2 * b][e], y[2 * aa + 1][2 * b + 1][e]));
+                        v = v + bv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
+                        *reinterpret_cast<f32x4*>(op + ((size_t)aa * (W >> 1) + b) * Cout) = v;
                     }
             } else {
+                float* op = a.out + (((size_t)f * H + oy) * W + ox) * Cout + n;
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        a.out[(((size_t)f * H + oy + aa) * W + ox + b) * Cout + n] = fmaxf(y[aa][b] + bv, 0.f);
+                    for (int b = 0; b < 4; ++b) {
+                        f32x4 v = y[aa][b] + bv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
+                        *reinterpret_cast<f32x4*>(op + ((size_t)aa * W + b) * Cout) = v;
+                    }
             }
         }
         W43_STAMP(22);
