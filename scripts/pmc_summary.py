@@ -30,7 +30,8 @@ def main():
                 k = row["Kernel_Name"]
                 if a.match and a.match not in k:
                     continue
-                k = k.replace("void ", "").split("(")[0]
+                k = k.replace("void ", "").replace("(anonymous namespace)::", "")
+                k = k.split("(")[0]
                 cell = acc[k][row["Counter_Name"]]
                 cell[0] += float(row["Counter_Value"])
                 cell[1].add(row["Dispatch_Id"])
