@@ -199,7 +199,10 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int vabase = wave * 9 * 256 + mrow * 8 + ((kh ^ ((mrow >> 3) & 1)) * 4);                   // floats, + j * 256
     const int n8 = Cin / 8;
 
-    f32x16 acc[8][2], accv[2];                 // planes 0..7 (accumulation registers), plane 8 (VGPRs, w43_mfma_v)
+    // planes 0..7 (accumulation registers), plane 8 (VGPRs, w43_mfma_v).  Work balance: the two waves with the heavy transform
+    // tasks (rows (1,2), (3,4): +90 VALU, +12 LDS instructions per K step) hand the second column half of their last plane
+    // (4 MFMAs = 256 cycles per K step) to the wave two above them, which accumulates it in accx.
+    f32x16 acc[8][2], accv[2], accx;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -210,6 +213,8 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accv[nb][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[r] = 0.f;
 
     // ---- K loop, specialised by the wave's transform task (ROLE = wave: 0 plane rows (1,2), 1 rows (3,4), 2 row 0, 3 row 5;
     // the pairs share their row pass).  The dispatch is hoisted out of the loop: four straight-line loop bodies.
@@ -286,18 +291,24 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // static); group G + 1 is requested when group G starts.  vmcnt retires in order, so the request order matters: the
         // U request precedes the K step's patch requests (HBM latency), which then only have to be back two groups later,
         // when they are stored.  A operand: ONE set, re-read for the next group right after a group's last MFMA has issued.
-        f32x4 Bq[2][3][2], Aq[3];
+        constexpr bool DONOR = ROLE <= 1;                               // gives (plane 8, half 1) to wave ROLE + 2
+        f32x4 Bq[2][3][2], Aq[3], Bx[2], Ax;
+        Bx[0] = Bx[1] = Ax = f32x4{0.f, 0.f, 0.f, 0.f};
         const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.U + ((size_t)cb * n8 * 4 + wave) * 4608), 0, (int)((size_t)n8 * 18432 * sizeof(float) - (size_t)wave * 4608 * sizeof(float)), 0x00020000);
-        const unsigned ulane = (unsigned)lane * 16u;                     // bytes
+            const_cast<float*>(a.U + (size_t)cb * n8 * 18432), 0, (int)((size_t)n8 * 18432 * sizeof(float)), 0x00020000);
+        const unsigned ulane = (unsigned)lane * 16u + (unsigned)ROLE * 18432u;          // bytes: + this wave's 4608 floats
+        const unsigned uxlane = (unsigned)lane * 16u + (unsigned)(ROLE & 1) * 18432u + 17u * 1024u;   // the donated unit
         auto load_B = [&](int c, int g, int set) {                        // K step c, plane group g
             const int sbase = c * 73728 + g * 6144;                       // bytes: 18432 floats per K step, 3 planes x 2 x 256 per group
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 Bq[set][pl][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane + (pl * 2) * 1024, sbase, 0));
-                Bq[set][pl][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane + (pl * 2 + 1) * 1024, sbase, 0));
+                if (!(DONOR && g == 2 && pl == 2))
+                    Bq[set][pl][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane + (pl * 2 + 1) * 1024, sbase, 0));
             }
+            if (!DONOR && g == 2) Bx[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uxlane, c * 73728, 0));
         };
+        const int vxbase = (9 * (ROLE & 1) + 8) * 256 + mrow * 8 + ((kh ^ ((mrow >> 3) & 1)) * 4);      // the donated plane's A operand
         load_B(0, 0, 0);
         W43_STAMP(18);
 
@@ -335,7 +346,10 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                 acc[3 * g + pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[bs][pl][1][q], acc[3 * g + pl][1], 0, 0, 0);
                             } else {
                                 w43_mfma_v(accv[0], Aq[pl][q], Bq[bs][pl][0][q]);
-                                w43_mfma_v(accv[1], Aq[pl][q], Bq[bs][pl][1][q]);
+                                if constexpr (!DONOR) {
+                                    w43_mfma_v(accv[1], Aq[pl][q], Bq[bs][pl][1][q]);
+                                    w43_mfma_v(accx, Ax[q], Bx[bs][q]);
+                                }
                             }
                         }
                     __builtin_amdgcn_sched_barrier(0);
@@ -350,6 +364,7 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         if (g < 2) {
 #pragma unroll
                             for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + (3 * (g + 1) + pl) * 256);
+                            if constexpr (!DONOR && !(W43_ABL & 16)) if (g == 1) Ax = *reinterpret_cast<const f32x4*>(s_V + PAR * VF + vxbase);
                         } else {
                             if constexpr (!(W43_ABL & 4)) stage_store(PAR);
                         }
@@ -386,11 +401,19 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W43_STAMP(19);
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
+            if (j == 8 && nb == 1 && wave < 2) continue;            // that unit was accumulated by wave + 2 (accx)
             const f32x16 v = j < 8 ? (nb == 0 ? acc[j][0] : acc[j][1]) : (nb == 0 ? accv[0] : accv[1]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
                 sZ[((9 * wave + j) * 32 + m) * 32 + col] = v[r];
+            }
+        }
+        if (nb == 1 && wave >= 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
+                sZ[((9 * (wave - 2) + 8) * 32 + m) * 32 + col] = accx[r];
             }
         }
         W43_STAMP(20);
