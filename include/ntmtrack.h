@@ -377,6 +377,18 @@ int ntk_serialize_sequential(const float* fmap, const float* gts0, float* X, int
 int ntk_heatmap_ce_loss(const float* logits, const float* gt, float* probs, float* loss, float* dlogits,
                         int B, int T, int F, void* stream);
 
+/* Two-step presentation + (F+1)-way head of main.py's ntm_two_step (:862-977; ntm_tracker_new.py:112-195 with
+ * two_step=True): a whole frame is ONE step, rows [switch, feat(D), target(F)]: step 0 = [0, feat_0, target], frame
+ * t >= 1 = the presentation step [0, feat_t, 0] then the query step [1, 0, 0]  ->  S = 2T - 1 steps.
+ * feat [B, T, D] (the flattened, optionally compressed feature map), target [B, F] (nullable), X [B, S, ldx], ldx >= 1 + D + F.
+ * Loss (:903-951): labels are the background row [0..0, 1] at step 0 and at every presentation step and [gt_t, 0] at the
+ * query step of frame t; they pass through a softmax before the cross entropy (as coded);
+ * loss = sum_rows CE(logits_row, softmax(label_row)) / ((2T - 1) B).  logits [B, S, F+1], gt [B, T, F] (row 0 unused),
+ * probs [B, S, F+1] (nullable), loss [1], dlogits [B, S, F+1] (nullable). */
+int ntk_serialize_two_step(const float* feat, const float* target, float* X, int B, int T, int D, int F, int ldx, void* stream);
+int ntk_two_step_ce_loss(const float* logits, const float* gt, float* probs, float* loss, float* dlogits,
+                         int B, int T, int F, void* stream);
+
 /* copy-task head (main.py:1603-1610, BASELINE configs[0]): loss = tf.losses.log_loss(labels,
  * sigmoid(logits)) (mean over all n elements, epsilon 1e-7) and d loss / d logits (nullable). */
 int ntk_log_loss(const float* logits, const float* labels, float* loss, float* dlogits, int n, void* stream);

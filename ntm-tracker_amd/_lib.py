@@ -81,6 +81,8 @@ def _sig(lib):
         "ntk_log_loss": (c_int, [P, P, P, P, c_int, P]),
         "ntk_serialize_sequential": (c_int, [P, P, P] + [c_int] * 5 + [P]),
         "ntk_heatmap_ce_loss": (c_int, [P] * 5 + [c_int] * 3 + [P]),
+        "ntk_serialize_two_step": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+        "ntk_two_step_ce_loss": (c_int, [P] * 5 + [c_int] * 3 + [P]),
         "ntk_ntm_init_state": (c_int, [P, P, c_int, c_int, c_int, P]),
         "ntk_ntm_init_state_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_global_norm_workspace_bytes": (c_size_t, [c_size_t]),

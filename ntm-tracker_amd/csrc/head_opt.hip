@@ -160,6 +160,79 @@ __global__ __launch_bounds__(1024) void heatmap_ce_loss_kernel(const float* __re
     }
 }
 
+// Two-step presentation of main.py's ntm_two_step (:862-977) / ntm_tracker_new.NTMTracker(two_step=True) (:112-195): a whole
+// frame is ONE step.  Rows [switch, feat(D), target(F)]: step 0 = [0, feat_0, target]; frame t >= 1 = [0, feat_t, 0] then the
+// query step [1, 0, 0]  ->  S = 2 T - 1 steps.  feat [B, T, D] (D a multiple of 4 is NOT required), target [B, F].
+__global__ void serialize_two_step_kernel(const float* __restrict__ feat, const float* __restrict__ target, float* __restrict__ X,
+                                          int B, int T, int D, int F, int ldx) {
+    const int S = 2 * T - 1;
+    const size_t total = (size_t)B * S * ldx;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % ldx);
+        const size_t r = idx / ldx;
+        const int s = (int)(r % S), b = (int)(r / S);
+        const bool query = s > 0 && (s & 1) == 0;               // steps 2, 4, ...: "ask for output"
+        const int t = (s + 1) >> 1;                              // frame shown at steps 0, 1, 3, 5, ...
+        float v = 0.f;
+        if (c == 0) v = query ? 1.f : 0.f;
+        else if (c <= D) v = query ? 0.f : feat[((size_t)b * T + t) * D + (c - 1)];
+        else if (c <= D + F) v = (s == 0 && target) ? target[(size_t)b * F + (c - 1 - D)] : 0.f;
+        X[idx] = v;
+    }
+}
+
+// Loss of ntm_two_step (main.py:903-951): labels [B, 2T-1, F+1] = background row [0..0,1] at step 0 and at every
+// presentation step, [gt_t, 0] at the query step of frame t >= 1; the labels pass through tf.nn.softmax before the cross
+// entropy (as coded); loss = sum_rows CE(logits_row, softmax(label_row)) / ((2T-1) B).  One wave per row.
+__global__ __launch_bounds__(1024) void two_step_ce_loss_kernel(const float* __restrict__ logits, const float* __restrict__ gt,
+                                                                 float* __restrict__ probs, float* __restrict__ loss,
+                                                                 float* __restrict__ dlogits, int B, int T, int F) {
+    __shared__ float red[16];
+    const int S = 2 * T - 1, K = F + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const float inv = 1.0f / ((float)S * (float)B);
+    float acc = 0.f;
+    for (int r = wave; r < B * S; r += nw) {
+        const int b = r / S, s = r - b * S;
+        const bool query = s > 0 && (s & 1) == 0;
+        const float* g = query ? gt + ((size_t)b * T + (s >> 1)) * F : nullptr;
+        const float* z = logits + (size_t)r * K;
+        // softmax of the label row (values 0/1, so no max subtraction is needed; done anyway for arbitrary heat-maps)
+        float lmx = query ? 0.f : 1.f;
+        if (query) { for (int i = lane; i < F; i += 64) lmx = fmaxf(lmx, g[i]); lmx = wave_max(lmx); }
+        float lse_l = 0.f, mx = -INFINITY;
+        for (int i = lane; i < K; i += 64) {
+            const float y = (i < F) ? (query ? g[i] : 0.f) : (query ? 0.f : 1.f);
+            lse_l += expf(y - lmx);
+            mx = fmaxf(mx, z[i]);
+        }
+        lse_l = wave_sum(lse_l); mx = wave_max(mx);
+        float se = 0.f;
+        for (int i = lane; i < K; i += 64) se += expf(z[i] - mx);
+        se = wave_sum(se);
+        const float lse = logf(se);
+        float ce = 0.f;
+        for (int i = lane; i < K; i += 64) {
+            const float y = (i < F) ? (query ? g[i] : 0.f) : (query ? 0.f : 1.f);
+            const float q = expf(y - lmx) / lse_l;               // softmax(labels)
+            const float lp = z[i] - mx - lse;
+            ce -= q * lp;
+            const float p = expf(lp);
+            if (probs) probs[(size_t)r * K + i] = p;
+            if (dlogits) dlogits[(size_t)r * K + i] = (p - q) * inv;
+        }
+        ce = wave_sum(ce);
+        if (lane == 0) acc += ce;
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float sacc = 0.f;
+        for (int w = 0; w < nw; ++w) sacc += red[w];
+        if (loss) *loss = sacc * inv;
+    }
+}
+
 // copy task head (main.py:1603-1610): p = sigmoid(logit); loss = mean(-(y log(p+eps) + (1-y) log(1-p+eps))), eps = 1e-7
 // (tf.losses.log_loss defaults); dlogits = d loss / d logit.  Single workgroup, fixed-order reduction.
 __global__ __launch_bounds__(1024) void log_loss_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
@@ -390,6 +463,27 @@ extern "C" int ntk_heatmap_ce_loss(const float* logits, const float* gt, float* 
     NTK_REQUIRE(B > 0 && T >= 2 && F > 0, NTK_ERR_BAD_SHAPE, "ntk_heatmap_ce_loss: B=%d T=%d (>= 2) F=%d", B, T, F);
     heatmap_ce_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, gt, probs, loss, dlogits, B, T, F);
     NTK_CHECK_LAUNCH("ntk_heatmap_ce_loss");
+    return NTK_OK;
+}
+
+extern "C" int ntk_serialize_two_step(const float* feat, const float* target, float* X, int B, int T, int D, int F, int ldx,
+                                      void* stream) {
+    NTK_REQUIRE(feat && X, NTK_ERR_BAD_PTR, "ntk_serialize_two_step: null pointer");
+    NTK_REQUIRE(B > 0 && T >= 1 && D > 0 && F > 0 && ldx >= 1 + D + F, NTK_ERR_BAD_SHAPE,
+                "ntk_serialize_two_step: B=%d T=%d D=%d F=%d ldx=%d (>= 1 + D + F)", B, T, D, F, ldx);
+    const size_t total = (size_t)B * (2 * T - 1) * ldx;
+    const unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    serialize_two_step_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(feat, target, X, B, T, D, F, ldx);
+    NTK_CHECK_LAUNCH("ntk_serialize_two_step");
+    return NTK_OK;
+}
+
+extern "C" int ntk_two_step_ce_loss(const float* logits, const float* gt, float* probs, float* loss, float* dlogits,
+                                    int B, int T, int F, void* stream) {
+    NTK_REQUIRE(logits && gt && (loss || dlogits || probs), NTK_ERR_BAD_PTR, "ntk_two_step_ce_loss: null pointer");
+    NTK_REQUIRE(B > 0 && T >= 1 && F > 0, NTK_ERR_BAD_SHAPE, "ntk_two_step_ce_loss: B=%d T=%d F=%d", B, T, F);
+    two_step_ce_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, gt, probs, loss, dlogits, B, T, F);
+    NTK_CHECK_LAUNCH("ntk_two_step_ce_loss");
     return NTK_OK;
 }
 

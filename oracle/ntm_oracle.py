@@ -471,3 +471,45 @@ def vgg16_conv43_bf16(frames, weights):
             y = maxpool2x2(y)
         x = bf16_round(y.astype(np.float32))
     return x
+
+
+# ---- two-step presentation (main.py:862-977; ntm_tracker_new.py:112-195 with two_step=True)
+def two_step_inputs(feat, target):
+    """feat [B, T, D] (flattened, optionally compressed feature map of every frame), target [B, F] -> X [B, 2T-1, 1+D+F]:
+    step 0 = [0, feat_0, target]; frame t >= 1 = [0, feat_t, 0] then the query step [1, 0, 0]
+    (ntm_tracker_new.py:150-181: concat([switch, inputs, target]))."""
+    B, T, D = feat.shape
+    F = target.shape[1]
+    X = np.zeros((B, 2 * T - 1, 1 + D + F), feat.dtype)
+    X[:, 0, 1:1 + D] = feat[:, 0]
+    X[:, 0, 1 + D:] = target
+    for t in range(1, T):
+        X[:, 2 * t - 1, 1:1 + D] = feat[:, t]
+        X[:, 2 * t, 0] = 1
+    return X
+
+
+def two_step_labels(gt):
+    """gt [B, T, F] -> labels [B, 2T-1, F+1] (main.py:903-934): the first frame and every presentation step carry the
+    background row [0..0, 1]; the query step of frame t >= 1 carries [gt_t, 0]."""
+    B, T, F = gt.shape
+    lab = np.zeros((B, 2 * T - 1, F + 1), gt.dtype)
+    lab[:, 0, F] = 1
+    for t in range(1, T):
+        lab[:, 2 * t - 1, F] = 1
+        lab[:, 2 * t, :F] = gt[:, t]
+    return lab
+
+
+def two_step_ce_loss(logits, gt):
+    """main.py:943-947: sum softmax_cross_entropy_with_logits(logits, SOFTMAX(labels)) / ((2T-1) B) -- the labels pass
+    through tf.nn.softmax as coded.  Returns (loss, probs, dlogits)."""
+    B, S, K = logits.shape
+    lab = two_step_labels(gt)
+    q = np.exp(lab - lab.max(-1, keepdims=True)); q /= q.sum(-1, keepdims=True)
+    z = logits - logits.max(-1, keepdims=True)
+    lp = z - np.log(np.exp(z).sum(-1, keepdims=True))
+    loss = -(q * lp).sum() / (S * B)
+    p = np.exp(lp)
+    return loss, p, (p - q) / (S * B)
+

@@ -228,3 +228,26 @@ def test_sequential_serialisation_layout():
     loss, p = O.heatmap_ce_loss(np.zeros((B, x.shape[1], 1)), np.full((B, T - 1, F), 1.0 / F), T)
     np.testing.assert_allclose(loss, B * np.log(F))              # uniform scores: (T-1) B log F / (T-1)
     np.testing.assert_allclose(p, 1.0 / F)
+
+
+def test_two_step_layout_known_answers():
+    """main.py:903-934 / ntm_tracker_new.py:150-181 on a hand-written case: T = 3 frames, F = 2 positions, D = 2."""
+    feat = np.arange(12, dtype=np.float32).reshape(1, 3, 4)[:, :, :2] + 1          # frames [1,2], [5,6], [9,10]
+    target = np.array([[0.25, 0.75]], np.float32)
+    X = O.two_step_inputs(feat, target)
+    assert X.shape == (1, 5, 5)
+    np.testing.assert_array_equal(X[0], np.array([[0, 1, 2, 0.25, 0.75],        # frame 0 with the target
+                                                   [0, 5, 6, 0, 0],              # frame 1 shown
+                                                   [1, 0, 0, 0, 0],              # ... and asked for
+                                                   [0, 9, 10, 0, 0],
+                                                   [1, 0, 0, 0, 0]], np.float32))
+    gt = np.array([[[9, 9], [1, 0], [0, 1]]], np.float32)                          # row 0 (the target frame) is not a label
+    lab = O.two_step_labels(gt)
+    np.testing.assert_array_equal(lab[0], np.array([[0, 0, 1], [0, 0, 1], [1, 0, 0], [0, 0, 1], [0, 1, 0]], np.float32))
+    # the loss softmaxes the labels (as coded): a one-hot row becomes [e, 1, 1] / (e + 2)
+    logits = np.zeros((1, 5, 3))
+    loss, p, dl = O.two_step_ce_loss(logits, gt.astype(np.float64))
+    assert abs(loss - np.log(3.0)) < 1e-12 and np.allclose(p, 1 / 3)             # uniform logits: CE = log 3 whatever the labels
+    q = np.exp([0, 0, 1.0]) / (np.e + 2)
+    np.testing.assert_allclose(dl[0, 0], (1 / 3 - q) / 5, atol=1e-15)
+

@@ -1,0 +1,85 @@
+"""GPU: the two-step presentation (one step per frame + one query step, 2T - 1 steps) and its (F + 1)-way head with
+softmax cross entropy on softmaxed labels (main.py's ntm_two_step, :862-977; ntm_tracker_new.py:112-195) against the
+oracle restatement (oracle/ntm_oracle.py: two_step_inputs / two_step_labels / two_step_ce_loss, gradients from torch
+autograd).  Parity unpinned: the reference holds no fixture for this variant."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ntm_oracle as O
+from oracle import ntm_oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_step_serialiser_is_bit_exact(cuda):
+    from ntmtrack import twostep
+    rng = np.random.default_rng(3)
+    B, T, D, F = 3, 4, 37, 9
+    feat = rng.standard_normal((B, T, D)).astype(np.float32)
+    target = rng.uniform(0, 1, size=(B, F)).astype(np.float32)
+    ref = O.two_step_inputs(feat, target)
+    assert ref.shape == (B, 2 * T - 1, 1 + D + F)
+    X = twostep.serialize_two_step(torch.from_numpy(feat).to(cuda), torch.from_numpy(target).to(cuda), 48).cpu().numpy()
+    assert np.array_equal(X[:, :, :1 + D + F], ref) and not X[:, :, 1 + D + F:].any()
+    # layout contract (ntm_tracker_new.py:150-181): presentation steps carry switch 0, query steps switch 1 and nothing else
+    assert X[0, 2, 0] == 1 and not X[0, 2, 1:].any() and X[0, 1, 0] == 0 and np.array_equal(X[0, 1, 1:1 + D], feat[0, 1])
+    assert np.array_equal(X[:, 0, 1 + D:1 + D + F], target) and not X[:, 1:, 1 + D:].any()
+
+
+def test_two_step_ce_loss_and_gradient_match_oracle(cuda):
+    from ntmtrack import twostep
+    rng = np.random.default_rng(4)
+    B, T, F = 3, 4, 49
+    logits = (rng.standard_normal((B, 2 * T - 1, F + 1)) * 2).astype(np.float32)
+    gt = (rng.uniform(0, 1, size=(B, T, F)) > 0.8).astype(np.float32)                 # 0/1 heat-maps, as the reference's
+    gt[0, 1] = rng.uniform(0, 3, size=F).astype(np.float32)                           # ... and an arbitrary one
+    loss_ref, probs_ref, dl_ref = O.two_step_ce_loss(logits.astype(np.float64), gt.astype(np.float64))
+    lt = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    q = torch.softmax(torch.tensor(O.two_step_labels(gt.astype(np.float64))), dim=2)
+    l2 = -(q * torch.log_softmax(lt, dim=2)).sum() / ((2 * T - 1) * B)
+    l2.backward()
+    np.testing.assert_allclose(float(l2.detach()), loss_ref, rtol=1e-12)
+    np.testing.assert_allclose(lt.grad.numpy(), dl_ref, atol=1e-14)
+    loss, probs, dlog = twostep.two_step_ce_loss(torch.from_numpy(logits).to(cuda), torch.from_numpy(gt).to(cuda))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-5)
+    np.testing.assert_allclose(probs.cpu().numpy(), probs_ref, atol=1e-6)
+    np.testing.assert_allclose(dlog.cpu().numpy(), dl_ref, atol=1e-7)
+
+
+def test_two_step_tracker_gradients_and_learning(cuda):
+    """End to end: loss and every gradient of the NTM under the two-step presentation vs torch autograd on the oracle,
+    then a few optimiser steps on one batch lower the loss."""
+    from ntmtrack import twostep
+    B, T, F, D = 2, 3, 9, 36
+    rng = np.random.default_rng(6)
+    trk = twostep.NTMTwoStepTracker(B, T, F, D, mem_size=64, mem_dim=8, hidden_size=32, read_head_size=2, write_head_size=1,
+                                    write_first=True, init_scale=0.2, learning_rate=3e-3, device=cuda, seed=5)
+    sd = {k: v.numpy() for k, v in trk.cell.state_dict().items()}
+    cfg = O.NTMConfig(1 + D + F, F + 1, mem_size=64, mem_dim=8, shift_range=1, controller_hidden_size=32, controller_num_layers=1,
+                      write_head_size=1, read_head_size=2, write_first=True)
+    feat = np.maximum(rng.standard_normal((B, T, D)), 0).astype(np.float32)
+    gts = (rng.uniform(0, 1, size=(B, T, F)) > 0.7).astype(np.float32)
+    x = O.two_step_inputs(feat, gts[:, 0])
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    logits, _ = OT.loop(cfg, pt, torch.tensor(x, dtype=torch.float64))
+    q = torch.softmax(torch.tensor(O.two_step_labels(gts.astype(np.float64))), dim=2)
+    loss_ref = -(q * torch.log_softmax(logits, dim=2)).sum() / ((2 * T - 1) * B)
+    loss_ref.backward()
+    f, g = torch.from_numpy(feat).to(cuda), torch.from_numpy(gts).to(cuda)
+    loss, probs = trk.loss_and_grads(f, g)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), float(loss_ref.detach()), rtol=1e-4)
+    got = trk.cell.params.to_tf(grad=True)
+    gmax = max(float(np.abs(pt[k].grad.numpy()).max()) for k in sd)
+    for k in sorted(sd):
+        ref = pt[k].grad.numpy()
+        err = np.max(np.abs(got[k].numpy() - ref)) / max(np.max(np.abs(ref)), 1e-3 * gmax)
+        assert err < 3e-3, (k, err)
+    assert probs.shape == (B, 2 * T - 1, F + 1) and torch.allclose(probs.sum(2), torch.ones((B, 2 * T - 1), device=cuda), atol=1e-5)
+    first = float(loss.cpu())
+    for _ in range(30):
+        last = trk.train_step(f, g)
+    assert float(last.cpu()) < first
+    assert trk.infer(f, g[:, 0].contiguous()).shape == (B, T - 1, F + 1)
