@@ -288,7 +288,7 @@ int ntk_dnc_write_allocation_weights(const float* usage, const float* write_gate
  * read_mode | write_keys | write_strengths | read_keys | read_strengths] (row stride ldr); `act` receives each field
  * as a contiguous [B,width] array at act + B*offset(field).  _write_weights (:220-257), _erase_and_write (:32-63),
  * _read_weights (:259-303), read words (:151), and the whole step MemoryAccess._build (:113-158) = SURVEY's
- * ntk_dnc_access_step_fwd.  The step's backward is part of ntk_dnc_seq_bwd (no stand-alone form).
+ * ntk_dnc_access_step_fwd (its backward: ntk_dnc_access_step_bwd, below).
  * Workspaces (floats): write_weights 2*B*Wn*N + B*Wn; read_weights B*R*N*(1+2*Wn). */
 int ntk_dnc_interface_activations(const float* raw, int ldr, float* act, int B, int N, int W, int R, int Wn, void* stream);
 int ntk_dnc_write_weights(const float* memory, const float* usage, const float* write_keys, const float* write_strengths,
@@ -305,6 +305,20 @@ int ntk_dnc_access_step_fwd(const float* iface_raw, int ldr, const float* memory
                             const float* write_weights, const float* link, const float* precedence, const float* usage,
                             float* memory_out, float* read_weights_out, float* write_weights_out, float* link_out,
                             float* precedence_out, float* usage_out, float* read_words, float* workspace,
+                            int B, int N, int W, int R, int Wn, void* stream);
+
+/* Backward of one MemoryAccess step at module granularity (what tf.gradients gives dnc/access_test.py:145-159).  The step
+ * is recomputed from the PREVIOUS state and the raw interface; d_read_words [B,R,W] is the gradient w.r.t. the step's read
+ * words; g_memory [B,N,W], g_read_weights [B,R,N], g_link [B,Wn,N,N], g_precedence [B,Wn,N], g_usage [B,N] are IN/OUT: in =
+ * gradient w.r.t. the NEW state's field (zeros when the loss does not see it), out = gradient w.r.t. the previous state's
+ * (write weights get none: they reach the next usage under stop_gradient only, addressing.py:302).  d_iface_raw [B,IP]
+ * (IP from ntk_dnc_padded_dims): gradient w.r.t. the raw interface; the ten linears' gradients are GEMMs over it.
+ * N and W multiples of 4, R <= 4, Wn <= 4.  Workspace: ntk_dnc_access_step_bwd_workspace_bytes. */
+size_t ntk_dnc_access_step_bwd_workspace_bytes(int B, int N, int W, int R, int Wn);
+int ntk_dnc_access_step_bwd(const float* iface_raw, int ldr, const float* memory, const float* read_weights,
+                            const float* write_weights, const float* link, const float* precedence, const float* usage,
+                            const float* d_read_words, float* g_memory, float* g_read_weights, float* g_link,
+                            float* g_precedence, float* g_usage, float* d_iface_raw, float* workspace,
                             int B, int N, int W, int R, int Wn, void* stream);
 
 /* Full BPTT through a recorded DNC sequence (num_writes 1..4: one write head runs the tuned kernel, 2..4 the

@@ -57,6 +57,8 @@ def _sig(lib):
         "ntk_dnc_read_words": (c_int, [P] * 3 + [c_int] * 4 + [P]),
         "ntk_dnc_access_step_workspace_bytes": (ctypes.c_size_t, [c_int] * 5),
         "ntk_dnc_access_step_fwd": (c_int, [P, c_int] + [P] * 14 + [c_int] * 5 + [P]),
+        "ntk_dnc_access_step_bwd_workspace_bytes": (ctypes.c_size_t, [c_int] * 5),
+        "ntk_dnc_access_step_bwd": (c_int, [P, c_int] + [P] * 14 + [c_int] * 5 + [P]),
         "ntk_ntm_cosine_similarity": (c_int, [P] * 3 + [c_int] * 5 + [P]),
         "ntk_ntm_circular_convolution": (c_int, [P] * 3 + [c_int] * 4 + [P]),
         "ntk_ntm_step_fwd": (c_int, [c_int] * 9 + [P] * 24),

@@ -365,3 +365,133 @@ extern "C" int ntk_dnc_access_step_fwd(const float* iface_raw, int ldr, const fl
                                    N, W, R, Wn, stream))) return rc;
     return ntk_dnc_read_words(read_weights_out, memory_out, read_words, B, N, W, R, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of ONE MemoryAccess step at module granularity (what tf.gradients gives dnc/access_test.py:145-159: the
+// gradient of a function of the step's outputs w.r.t. the raw interface and the previous memory / read weights / link /
+// precedence / usage).  The step is recomputed from the previous state with the module kernels above into the record
+// layout of the sequence BPTT kernels, which then run for S = 1 with a dummy 4-unit controller whose weights are zero:
+// upstream gradients enter through the carried-gradient buffers (carry_in), previous-state gradients leave through them.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct AccessBwdWs {
+    size_t act, rows, usage, ww, wws, M, L, prec, rws, rw, WrT, WiT, Wy, gates, c, hc0, ypre, dout, dgates, dypre, gcarry, total;
+    int ldkT, ncar;
+};
+
+void access_bwd_ws(const DncDims& d, AccessBwdWs& w) {
+    const size_t B = d.B, N = d.N, W = d.W, R = d.R, Wn = d.Wn, hid = d.hid;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+    w.ldkT = (d.K + 3) & ~3;
+    w.ncar = (int)(Wn * N + N + R * N + w.ldkT + hid);
+    w.act = take(B * d.IP); w.rows = take(B * d.IP); w.usage = take(B * N); w.ww = take(B * Wn * N);
+    w.wws = take(2 * B * Wn * N + B * Wn); w.M = take(B * N * W); w.L = take(B * Wn * N * N); w.prec = take(B * Wn * N);
+    w.rws = take(B * R * N * (1 + 2 * Wn)); w.rw = take(B * R * N);
+    w.WrT = take(4 * hid * w.ldkT); w.WiT = take((size_t)d.IP * 4); w.Wy = take((size_t)d.ldy * d.OP);
+    w.gates = take(B * 4 * hid); w.c = take(B * hid); w.hc0 = take(B * 2 * hid); w.ypre = take(B * d.O); w.dout = take(B * d.O);
+    w.dgates = take(B * 4 * hid); w.dypre = take(B * d.OP); w.gcarry = take(B * w.ncar);
+    w.total = o;
+}
+
+// field-major activations (field f of every batch element contiguous) -> one interface row per batch element, in the
+// sequence kernels' record convention
+__global__ void ifc_rows_kernel(const float* __restrict__ act, float* __restrict__ rows, DncDims d) {
+    const int offs[11] = {d.oV, d.oE, d.oF, d.oAg, d.oWg, d.oRm, d.oKw, d.oBw, d.oKr, d.oBr, d.I};
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < d.B * d.IP; idx += gridDim.x * blockDim.x) {
+        const int b = idx / d.IP, c = idx - b * d.IP;
+        float v = 0.f;
+        if (c < d.I) {
+            int f = 0;
+            while (c >= offs[f + 1]) ++f;
+            const int width = offs[f + 1] - offs[f];
+            v = act[(size_t)d.B * offs[f] + (size_t)b * width + (c - offs[f])];
+            // the module activations leave the strengths raw (CosineWeights applies softplus itself, addressing.py:96-101);
+            // the sequence kernels record them activated
+            if (f == 7 || f == 9) v = dnc_softplus(v);
+        }
+        rows[idx] = v;
+    }
+}
+
+// carried-gradient rows [precedence (Wn N) | usage (N) | read weights (R N) | d[reads ; h] (ldkT) | cell (hid)]
+__global__ void access_carry_kernel(float* __restrict__ gcarry, float* __restrict__ g_prec, float* __restrict__ g_usage,
+                                    float* __restrict__ g_rw, const float* __restrict__ d_reads, int B, int N, int R, int Wn,
+                                    int RW, int ncar, int scatter) {
+    const int HN = Wn * N, RN = R * N;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * ncar; idx += gridDim.x * blockDim.x) {
+        const int b = idx / ncar, c = idx - b * ncar;
+        if (scatter) {
+            if (c < HN) g_prec[(size_t)b * HN + c] = gcarry[idx];
+            else if (c < HN + N) g_usage[(size_t)b * N + (c - HN)] = gcarry[idx];
+            else if (c < HN + N + RN) g_rw[(size_t)b * RN + (c - HN - N)] = gcarry[idx];
+        } else {
+            float v = 0.f;
+            if (c < HN) v = g_prec[(size_t)b * HN + c];
+            else if (c < HN + N) v = g_usage[(size_t)b * N + (c - HN)];
+            else if (c < HN + N + RN) v = g_rw[(size_t)b * RN + (c - HN - N)];
+            else if (c < HN + N + RN + RW) v = d_reads[(size_t)b * RW + (c - HN - N - RN)];
+            gcarry[idx] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ntk_dnc_access_step_bwd_workspace_bytes(int B, int N, int W, int R, int Wn) {
+    DncDims d;
+    dnc_fill_dims(d, B, 1, N, W, R, Wn, 4, 1, 0.f);
+    AccessBwdWs w;
+    access_bwd_ws(d, w);
+    return w.total * sizeof(float);
+}
+
+extern "C" int ntk_dnc_access_step_bwd(const float* iface_raw, int ldr, const float* memory, const float* read_weights,
+                                       const float* write_weights, const float* link, const float* precedence,
+                                       const float* usage, const float* d_read_words, float* g_memory, float* g_read_weights,
+                                       float* g_link, float* g_precedence, float* g_usage, float* d_iface_raw,
+                                       float* workspace, int B, int N, int W, int R, int Wn, void* stream) {
+    NTK_REQUIRE(iface_raw && memory && read_weights && write_weights && link && precedence && usage && d_read_words && g_memory &&
+                    g_read_weights && g_link && g_precedence && g_usage && d_iface_raw && workspace,
+                NTK_ERR_BAD_PTR, "ntk_dnc_access_step_bwd: null pointer");
+    NTK_REQUIRE(B > 0 && N >= 4 && (N % 4) == 0 && W >= 4 && (W % 4) == 0 && R >= 1 && R <= 4 && Wn >= 1 && Wn <= 4,
+                NTK_ERR_UNSUPPORTED, "ntk_dnc_access_step_bwd: N=%d W=%d (multiples of 4) R=%d (1..4) Wn=%d (1..4)", N, W, R, Wn);
+    DncDims d;
+    dnc_fill_dims(d, B, 1, N, W, R, Wn, 4, 1, 0.f);
+    AccessBwdWs w;
+    access_bwd_ws(d, w);
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = workspace;
+    auto f = [&](int off) { return ws + w.act + (size_t)B * off; };
+    if (hipMemsetAsync(ws + w.WrT, 0, (w.gcarry - w.WrT) * sizeof(float), st) != hipSuccess) return NTK_ERR_HIP;   // dummies, zero dout
+    int rc;
+    // the step, recomputed into the record layout
+    if ((rc = ntk_dnc_interface_activations(iface_raw, ldr, ws + w.act, B, N, W, R, Wn, stream))) return rc;
+    ifc_rows_kernel<<<(B * d.IP + 255) / 256, 256, 0, st>>>(ws + w.act, ws + w.rows, d);
+    if ((rc = ntk_dnc_freeness(write_weights, f(d.oF), read_weights, usage, ws + w.usage, B, N, Wn, R, stream))) return rc;
+    if ((rc = ntk_dnc_write_weights(memory, ws + w.usage, f(d.oKw), f(d.oBw), f(d.oAg), f(d.oWg), ws + w.ww, ws + w.wws, B, N, W, Wn,
+                                    stream))) return rc;
+    if ((rc = ntk_dnc_erase_and_write(memory, ws + w.ww, f(d.oE), f(d.oV), ws + w.M, B, N, W, Wn, stream))) return rc;
+    if ((rc = ntk_dnc_linkage(link, precedence, ws + w.ww, ws + w.L, ws + w.prec, B, N, Wn, stream))) return rc;
+    if ((rc = ntk_dnc_read_weights(ws + w.M, read_weights, ws + w.L, f(d.oKr), f(d.oBr), f(d.oRm), ws + w.rw, ws + w.rws, B, N, W, R, Wn,
+                                   stream))) return rc;
+    // upstream gradients -> carried-gradient rows
+    access_carry_kernel<<<(B * w.ncar + 255) / 256, 256, 0, st>>>(ws + w.gcarry, g_precedence, g_usage, g_read_weights, d_read_words, B, N,
+                                                                 R, Wn, R * W, w.ncar, 0);
+    NTK_CHECK_LAUNCH("ntk_dnc_access_step_bwd(setup)");
+    const float* cw = ws + w.wws;
+    const float* al = cw + (size_t)B * Wn * N;
+    const float* cr = ws + w.rws;
+    const float* fw = cr + (size_t)B * R * N;
+    const float* bw = fw + (size_t)B * R * Wn * N;
+    rc = ntk_dnc_seq_bwd(B, 1, N, W, R, Wn, 4, 1, 0.f, ws + w.WrT, w.ldkT, ws + w.WiT, 4, ws + w.Wy, memory, link, usage, read_weights,
+                         write_weights, precedence, ws + w.hc0, ws + w.gates, ws + w.c, ws + w.rows, ws + w.usage, ws + w.ww, ws + w.rw, cw, cr,
+                         al, ws + w.prec, fw, bw, ws + w.M, ws + w.L, ws + w.ypre, ws + w.dout, g_memory, g_link, ws + w.dgates, d_iface_raw,
+                         ws + w.dypre, ws + w.gcarry, 1, stream);
+    if (rc) return rc;
+    access_carry_kernel<<<(B * w.ncar + 255) / 256, 256, 0, st>>>(ws + w.gcarry, g_precedence, g_usage, g_read_weights, d_read_words, B, N,
+                                                                 R, Wn, R * W, w.ncar, 1);
+    NTK_CHECK_LAUNCH("ntk_dnc_access_step_bwd");
+    return NTK_OK;
+}

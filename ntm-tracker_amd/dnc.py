@@ -572,7 +572,7 @@ class Freeness(object):
 class MemoryAccess(object):
     """dnc/access.py:66-303 -- MemoryAccess(memory_size=128, word_size=20, num_reads=1, num_writes=1), callable on its
     own: ``module(inputs [B,D], AccessState) -> (read_words [B,R,W], AccessState)``; the reference's tests also call
-    ``_read_inputs``, ``_write_weights`` and ``_read_weights`` directly.  Forward only; parameters carry the Sonnet
+    ``_read_inputs``, ``_write_weights`` and ``_read_weights`` directly.  Forward through the module kernels, module-granular gradients through ``step_gradients``; parameters carry the Sonnet
     names ``memory_access/<linear>/{w,b}``.  (Training runs through the fused DNC core.)"""
 
     def __init__(self, memory_size=128, word_size=20, num_reads=1, num_writes=1, name="memory_access", input_dim=None,
@@ -692,6 +692,109 @@ class MemoryAccess(object):
                      _f32(inputs["read_mode"], dev))
         _lib.check(_lib.lib().ntk_dnc_read_weights(_P(m), _P(prw), _P(L), _P(k), _P(s_), _P(rm), _P(out), _P(ws), B, N, W, R, Wn,
                                                    _lib.stream()), "ntk_dnc_read_weights")
+        return out
+
+    # ---- module-granular backward (what tf.gradients gives dnc/access_test.py:145-159)
+    def _word_fields(self):
+        """(offset, groups) of the interface fields that hold words, in the packed order."""
+        out, o = [], 0
+        for name, width in self.widths:
+            if name in ("write_vectors", "erase_vectors", "write_keys"):
+                out.append((o, self.Wn))
+            elif name == "read_keys":
+                out.append((o, self.R))
+            o += width
+        return out
+
+    def step_gradients(self, inputs, prev_state, d_read_words, d_state=None):
+        """Gradients of a scalar function of ONE step's outputs: d_read_words [B,R,W] = its gradient w.r.t. the read words,
+        d_state (optional AccessState; write_weights ignored) = w.r.t. the new state's fields.  Returns a dict with the
+        gradients w.r.t. 'inputs' [B,D], the previous state's 'memory', 'read_weights', 'link', 'precedence_weights',
+        'usage', and the parameters ('memory_access/<linear>/w', '/b').  One C-ABI call (ntk_dnc_access_step_bwd) + the
+        linear layers' GEMMs; word_size is zero padded to a multiple of 4 on the way in."""
+        dev, L = self.device, _lib.lib()
+        raw, B = self._raw_interface(inputs)
+        N, W, R, Wn = self.N, self.W, self.R, self.Wn
+        Wp = (W + 3) // 4 * 4
+        c = lambda t: _f32(t, dev).contiguous()
+
+        def padw(t):                                    # [..., W] -> [..., Wp]
+            if Wp == W:
+                return c(t)
+            out = torch.zeros(tuple(t.shape[:-1]) + (Wp,), device=dev)
+            out[..., :W] = _f32(t, dev)
+            return out
+        # interface rows in the padded-word layout
+        vals = [ctypes.c_int() for _ in range(8)]
+        _lib.check(L.ntk_dnc_padded_dims(N, Wp, R, Wn, 4, 1, *[ctypes.byref(v) for v in vals]), "ntk_dnc_padded_dims")
+        IPp = vals[1].value
+        if Wp == W:
+            rawp = raw
+        else:
+            rawp = torch.zeros((B, IPp), device=dev)
+            o = op = 0
+            words = dict(self._word_fields())
+            for _name, width in self.widths:
+                if o in words:
+                    g = words[o]
+                    rawp[:, op:op + g * Wp].view(B, g, Wp)[:, :, :W] = raw[:, o:o + width].reshape(B, g, W)
+                    op += g * Wp
+                else:
+                    rawp[:, op:op + width] = raw[:, o:o + width]
+                    op += width
+                o += width
+        z = lambda *sh: torch.zeros(sh, device=dev)
+        ds = d_state
+        g_mem = padw(ds.memory) if ds is not None else z(B, N, Wp)
+        g_rw = c(ds.read_weights).clone() if ds is not None else z(B, R, N)
+        g_link = c(ds.linkage.link).clone() if ds is not None else z(B, Wn, N, N)
+        g_prec = c(ds.linkage.precedence_weights).clone() if ds is not None else z(B, Wn, N)
+        g_usage = c(ds.usage).clone() if ds is not None else z(B, N)
+        if ds is not None and Wp == W:
+            g_mem = g_mem.clone()
+        mem = padw(prev_state.memory)
+        rw, ww = c(prev_state.read_weights), c(prev_state.write_weights)
+        link, prec, usage = c(prev_state.linkage.link), c(prev_state.linkage.precedence_weights), c(prev_state.usage)
+        dr = padw(d_read_words)
+        d_rawp = torch.empty((B, IPp), device=dev)
+        ws = torch.empty(L.ntk_dnc_access_step_bwd_workspace_bytes(B, N, Wp, R, Wn) // 4, device=dev)
+        _lib.check(L.ntk_dnc_access_step_bwd(_P(rawp), IPp, _P(mem), _P(rw), _P(ww), _P(link), _P(prec), _P(usage), _P(dr), _P(g_mem),
+                                             _P(g_rw), _P(g_link), _P(g_prec), _P(g_usage), _P(d_rawp), _P(ws), B, N, Wp, R, Wn,
+                                             _lib.stream()), "ntk_dnc_access_step_bwd")
+        # back to the module's own interface layout
+        if Wp == W:
+            d_raw = d_rawp
+        else:
+            d_raw = torch.zeros((B, self.IP), device=dev)
+            o = op = 0
+            words = dict(self._word_fields())
+            for _name, width in self.widths:
+                if o in words:
+                    g = words[o]
+                    d_raw[:, o:o + width] = d_rawp[:, op:op + g * Wp].view(B, g, Wp)[:, :, :W].reshape(B, width)
+                    op += g * Wp
+                else:
+                    d_raw[:, o:o + width] = d_rawp[:, op:op + width]
+                    op += width
+                o += width
+        # the ten linears: d_inputs = d_raw . W, dW = d_raw^T . inputs, db = d_raw^T . 1   (fp32 MFMA GEMMs)
+        X = torch.zeros((B, self.ldx), device=dev)
+        X[:, :self.D] = _f32(inputs, dev)
+        ones = torch.ones((B, 4), device=dev)
+        Wn_t = torch.empty((self.ldx, self.IP), device=dev)
+        _lib.check(L.ntk_transpose_pad(_P(self.WT), self.ldx, _P(Wn_t), self.IP, self.IP, self.ldx, _lib.stream()), "ntk_transpose_pad")
+        d_in = gemm_nt(d_raw, Wn_t)
+        dWT = torch.empty((self.IP, self.ldx), device=dev)
+        gemm_tn(d_raw, X, dWT)
+        db4 = torch.empty((self.IP, 4), device=dev)
+        gemm_tn(d_raw, ones, db4)
+        out = {"inputs": d_in[:, :self.D].contiguous(), "memory": g_mem[..., :W].contiguous(), "read_weights": g_rw, "link": g_link,
+               "precedence_weights": g_prec, "usage": g_usage}
+        o = 0
+        for name, width in self.widths:
+            out["memory_access/%s/w" % name] = dWT[o:o + width, :self.D].t().contiguous()
+            out["memory_access/%s/b" % name] = db4[o:o + width, 0].contiguous()
+            o += width
         return out
 
     def __call__(self, inputs, prev_state):

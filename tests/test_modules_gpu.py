@@ -266,3 +266,72 @@ def test_ops_circular_convolution_and_shift(cuda):
     np.testing.assert_array_equal(ops.batched_circular_convolution(w, ident, device=cuda).cpu().numpy(), w)
     for shift in (-2, -1, 0, 1, 3):
         np.testing.assert_array_equal(ops.circular_shift(w, shift, device=cuda).cpu().numpy(), O.circular_shift(w, shift))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# module-granular backward: dnc/access_test.py:145-159 (testGradients) differentiates sum(read words) of ONE MemoryAccess
+# step w.r.t. inputs, memory, read_weights, precedence and link.  Here: the analytic gradients of the HIP path
+# (ntk_dnc_access_step_bwd) against torch autograd on the float64 restatement, for the reference's own module shape
+# (memory 20, word 6 -> padded to 8, 2 reads, 3 writes) from a NON-degenerate state, and from the all-zero initial state
+# the reference's test uses.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("zero_state", [False, True], ids=["random_state", "initial_state"])
+@pytest.mark.parametrize("N,W,R,Wn", [(AN, AW, AR, AWn), (32, 8, 2, 1)], ids=["reference_shape_3_writes", "one_write"])
+def test_memory_access_step_gradients_match_autograd(cuda, N, W, R, Wn, zero_state):
+    from ntmtrack import dnc as G
+    from oracle import dnc_oracle_torch as DT
+    rng = np.random.default_rng(11)
+    B, Din = 2, 10
+    mod = G.MemoryAccess(N, W, R, Wn, input_dim=Din, device=cuda, seed=5)
+    sd = {k: v.numpy() * (3.0 if k.endswith("/w") else 1.0) for k, v in mod.state_dict().items()}
+    for k in sd:
+        if k.endswith("/b"):
+            sd[k] = rng.uniform(-0.3, 0.3, size=sd[k].shape).astype(np.float32)
+    mod.load_state_dict(sd)
+    cfg = D.AccessConfig(N, W, R, Wn)
+    f = lambda *s: rng.random(s).astype(np.float32)
+    if zero_state:
+        st = D.access_initial_state(cfg, B)
+    else:
+        usage = np.stack([rng.permutation(N) for _ in range(B)]).astype(np.float32) / N * 0.8 + 0.1     # no near-ties for the sort
+        rw = f(B, R, N); rw /= rw.sum(2, keepdims=True) + 1
+        ww = f(B, Wn, N); ww /= ww.sum(2, keepdims=True) + 1
+        prec = f(B, Wn, N); prec /= prec.sum(2, keepdims=True) + 1
+        link = f(B, Wn, N, N)
+        link /= np.maximum(link.sum(2, keepdims=True), 1); link /= np.maximum(link.sum(3, keepdims=True), 1)
+        link[:, :, np.arange(N), np.arange(N)] = 0
+        st = D.AccessState((f(B, N, W) - 0.5).astype(np.float32), rw, ww, D.TemporalLinkageState(link.astype(np.float32), prec), usage)
+    x = rng.standard_normal((B, Din)).astype(np.float32)
+    Gr = rng.standard_normal((B, R, W)).astype(np.float32)                # d loss / d read words (the reference's test: all ones)
+    # oracle: autograd through one access step.  float64, except from the all-zero state: there every usage is tied and
+    # the simulated usages of the later write heads are products of 1e-6 factors that underflow in float32 but not in
+    # float64 -- the two precisions allocate DIFFERENT slots (as the reference's float32 TF graph would), so that case is
+    # compared with the float32 restatement
+    odt = torch.float32 if zero_state else torch.float64
+    t64 = lambda v: torch.tensor(np.asarray(v), dtype=odt, requires_grad=True)
+    pt = {k: t64(v) for k, v in sd.items()}
+    xt = t64(x)
+    leaves = dict(memory=t64(st.memory), read_weights=t64(st.read_weights), link=t64(st.linkage.link),
+                  precedence_weights=t64(st.linkage.precedence_weights), usage=t64(st.usage))
+    ost = DT.AccessState(leaves["memory"], leaves["read_weights"], torch.tensor(st.write_weights, dtype=odt),
+                         DT.TemporalLinkageState(leaves["link"], leaves["precedence_weights"]), leaves["usage"])
+    reads, _new = DT.access_step(cfg, pt, xt, ost)
+    (reads * torch.tensor(Gr, dtype=odt)).sum().backward()
+    # HIP
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(cuda)
+    gst = G.AccessState(t(st.memory), t(st.read_weights), t(st.write_weights),
+                        G.TemporalLinkageState(t(st.linkage.link), t(st.linkage.precedence_weights)), t(st.usage))
+    out, _ = mod(t(x), gst)
+    np.testing.assert_allclose(out.cpu().numpy(), reads.detach().double().numpy(), atol=2e-5)
+    g = mod.step_gradients(t(x), gst, t(Gr))
+    torch.cuda.synchronize()
+    ref = {"inputs": xt.grad}
+    ref.update({k: v.grad for k, v in leaves.items()})
+    ref.update({k: v.grad for k, v in pt.items()})
+    scale = max(float(v.abs().max()) for v in ref.values() if v is not None)
+    for k in sorted(ref):
+        r = ref[k].double().numpy() if ref[k] is not None else np.zeros(tuple(g[k].shape))
+        got = g[k].cpu().numpy()
+        assert got.shape == r.shape, (k, got.shape, r.shape)
+        err = np.max(np.abs(got - r)) / max(np.max(np.abs(r)), 1e-3 * scale)
+        assert err < 3e-3, (k, err)
