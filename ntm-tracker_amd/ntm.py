@@ -694,3 +694,62 @@ class LoopNTMTracker(object):
         logits, outputs, new, rec = self.cell.run_sequence(X, state, record=record)
         self.last_state, self.last_record = new, rec
         return outputs, logits
+
+
+class PlainNTMTracker(object):
+    """ntm_tracker_new.py:66-110: the cell statically unrolled ``model_length`` times over [B, model_length, D] inputs,
+    nothing assumed about the inputs.  Same call signature; the unrolled graph becomes one persistent kernel launch.
+    Returns (outputs, output_logits, states, debugs): ``states`` holds the initial and the final state (the reference
+    keeps every step's; the per-step memories / head weights are in ``debugs`` = the recorded tensors [B,S,...])."""
+
+    def __init__(self, model_length, output_dim, initializer=None, **kwargs):
+        self.model_length = model_length
+        self.cell = NTMCell(output_dim, **kwargs)
+        self.initializer = initializer
+
+    def __call__(self, inputs, state=None, scope=None):
+        B, S, D = inputs.shape
+        if S != self.model_length:
+            raise _lib.NtkError("inputs have %d steps, tracker was built for %d" % (S, self.model_length))
+        if self.cell.dims is None:
+            self.cell._build(D)
+        X = self.cell._pad_inputs(inputs)
+        state = state or self.cell.zero_state(B, self.initializer)
+        logits, outputs, new, rec = self.cell.run_sequence(X, state, record=True)
+        debugs = {k: rec[k] for k in ("u", "wc", "wv", "w", "M", "read") if k in rec}
+        return outputs, logits, [state, new], debugs
+
+
+class NTMTracker(object):
+    """ntm_tracker_new.py:112-195: one step per frame, the target indicator appended to the frame's features: step 0 sees
+    [inputs_0, target], later steps [inputs_t, 0]; with ``two_step`` every later frame takes a presentation step
+    [0, inputs_t, 0] and a query step [1, 0, 0] (2T - 1 steps, see ntmtrack.twostep).  Same constructor and call
+    signature: ``tracker(inputs [B,T,D], target [B,F]) -> (outputs, output_logits, states, debugs)``."""
+
+    def __init__(self, sequence_length, batch_size, output_dim, initializer=None, two_step=False, **kwargs):
+        self.sequence_length, self.batch_size, self.output_dim = sequence_length, batch_size, output_dim
+        self.cell = NTMCell(output_dim, **kwargs)
+        self.initializer = initializer
+        self.two_step = two_step
+
+    def __call__(self, inputs, target, scope=None):
+        B, T, D = inputs.shape
+        F = target.shape[1]
+        if T != self.sequence_length or B != self.batch_size:
+            raise _lib.NtkError("inputs [%d,%d,..] do not match the tracker (batch %d, length %d)" % (B, T, self.batch_size, self.sequence_length))
+        if self.two_step:
+            from .twostep import serialize_two_step
+            if self.cell.dims is None:
+                self.cell._build(1 + D + F)
+            X = serialize_two_step(inputs, target, self.cell.input_ldx)
+        else:
+            if self.cell.dims is None:
+                self.cell._build(D + F)
+            X = torch.zeros((B, T, self.cell.input_ldx), device=inputs.device)
+            X[:, :, :D] = inputs
+            X[:, 0, D:D + F] = target                                    # the indicator: target at the first frame, zeros after
+        state = self.cell.zero_state(B, self.initializer)
+        logits, outputs, new, rec = self.cell.run_sequence(X, state, record=True)
+        debugs = {k: rec[k] for k in ("u", "wc", "wv", "w", "M", "read") if k in rec}
+        return outputs, logits, [state, new], debugs
+

@@ -83,3 +83,36 @@ def test_two_step_tracker_gradients_and_learning(cuda):
         last = trk.train_step(f, g)
     assert float(last.cpu()) < first
     assert trk.infer(f, g[:, 0].contiguous()).shape == (B, T - 1, F + 1)
+
+
+@pytest.mark.parametrize("two_step", [False, True], ids=["one_step_per_frame", "two_step"])
+def test_static_unroll_trackers_match_oracle(cuda, two_step):
+    """ntm_tracker_new.NTMTracker (one step per frame with the target indicator; two_step) and PlainNTMTracker mirrors:
+    logits of the single launch vs the oracle cell looped over the same rows."""
+    from ntmtrack.ntm import NTMTracker, PlainNTMTracker
+    rng = np.random.default_rng(8)
+    B, T, D, F = 2, 4, 20, 9
+    kw = dict(mem_size=64, mem_dim=8, controller_hidden_size=32, controller_num_layers=1, read_head_size=2, write_head_size=1)
+    trk = NTMTracker(T, B, F + 1, two_step=two_step, device=cuda, seed=3, **kw)
+    feat = rng.standard_normal((B, T, D)).astype(np.float32)
+    target = rng.uniform(0, 1, size=(B, F)).astype(np.float32)
+    outputs, logits, states, debugs = trk(torch.from_numpy(feat).to(cuda), torch.from_numpy(target).to(cuda))
+    if two_step:
+        x = O.two_step_inputs(feat, target)
+    else:
+        x = np.concatenate([feat, np.zeros((B, T, F), np.float32)], 2)
+        x[:, 0, D:] = target
+    cfg = O.NTMConfig(x.shape[2], F + 1, mem_size=64, mem_dim=8, shift_range=1, controller_hidden_size=32, controller_num_layers=1,
+                      write_head_size=1, read_head_size=2)
+    sd = {k: v.numpy() for k, v in trk.cell.state_dict().items()}
+    out_ref, logits_ref, fin = O.loop_ntm_tracker(cfg, sd, x)
+    torch.cuda.synchronize()
+    assert logits.shape == (B, x.shape[1], F + 1) and len(states) == 2
+    np.testing.assert_allclose(logits.cpu().numpy(), logits_ref, atol=2e-5)
+    np.testing.assert_allclose(outputs.cpu().numpy(), out_ref, atol=2e-5)
+    np.testing.assert_allclose(states[1]["M"].cpu().numpy(), fin["M"], atol=2e-5)
+    assert debugs["M"].shape[:2] == (B, x.shape[1])
+    # PlainNTMTracker on the same rows gives the same thing
+    plain = PlainNTMTracker(x.shape[1], F + 1, device=cuda, seed=3, **kw)
+    o2, l2, _s, _d = plain(torch.from_numpy(x).to(cuda))
+    assert torch.equal(l2, logits) and torch.equal(o2, outputs)
