@@ -318,6 +318,9 @@ class NTMCell(object):
         rec["xproj"] = xproj
         return logits, outputs, new, rec
 
+    want_input_grad = False
+    last_dX = None
+
     def backward_sequence(self, X, state0, rec, dlogits, dfinal=None, workspace=None):
         """BPTT through a recorded sequence: fills ``self.params.grad`` (kernel layout) with
         d loss / d params given ``dlogits`` [B,S,O] (and optionally gradients w.r.t. the final
@@ -354,6 +357,13 @@ class NTMCell(object):
         gemm_tn(dgates.view(BS, 4 * d.hid), X.view(BS, d.ldx), P.view("WxT", grad=True), workspace=workspace)
         gemm_tn(rec["z"].view(BS, d.ldz), dgates.view(BS, 4 * d.hid), P.view("Wr", grad=True), workspace=workspace)
         gemm_tn(rec["h"].view(BS, d.ldh), du.view(BS, d.PP), P.view("Wa", grad=True), workspace=workspace)
+        #: gradient w.r.t. the (padded) input rows, for callers with a trainable layer in front of the cell (the input
+        #: compressor of main.py's trackers): dX = dgates . Wx, one more GEMM -- only when asked for
+        self.last_dX = None
+        if self.want_input_grad:
+            Wx = torch.empty((d.ldx, 4 * d.hid), device=dev)
+            _lib.check(L.ntk_transpose_pad(_P(P.view("WxT")), d.ldx, _P(Wx), 4 * d.hid, 4 * d.hid, d.ldx, st), "ntk_transpose_pad")
+            self.last_dX = gemm_nt(dgates.view(BS, 4 * d.hid), Wx).view(B, S, d.ldx)
         return g0
 
     def init_state_backward(self, g0, batch_size):

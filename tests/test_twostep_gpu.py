@@ -116,3 +116,46 @@ def test_static_unroll_trackers_match_oracle(cuda, two_step):
     plain = PlainNTMTracker(x.shape[1], F + 1, device=cuda, seed=3, **kw)
     o2, l2, _s, _d = plain(torch.from_numpy(x).to(cuda))
     assert torch.equal(l2, logits) and torch.equal(o2, outputs)
+
+
+def test_two_step_tracker_with_input_compressor_gradients(cuda):
+    """main.py:882-887: a 1x1 convolution compresses the feature map in front of the two-step tracker and trains with it:
+    loss, the compressor's weight gradient and the cell's gradients vs torch autograd on the oracle."""
+    from ntmtrack import twostep
+    B, T, F, C, Cd = 2, 3, 9, 16, 4
+    rng = np.random.default_rng(9)
+    comp = twostep.InputCompressor(C, Cd, device=cuda, seed=2)
+    trk = twostep.NTMTwoStepTracker(B, T, F, F * Cd, mem_size=64, mem_dim=8, hidden_size=32, read_head_size=2, write_head_size=1,
+                                    init_scale=0.2, device=cuda, seed=5, compressor=comp)
+    sd = {k: v.numpy() for k, v in trk.cell.state_dict().items()}
+    cfg = O.NTMConfig(1 + F * Cd + F, F + 1, mem_size=64, mem_dim=8, shift_range=1, controller_hidden_size=32, controller_num_layers=1,
+                      write_head_size=1, read_head_size=2)
+    fmap = np.maximum(rng.standard_normal((B, T, F, C)), 0).astype(np.float32)
+    gts = (rng.uniform(0, 1, size=(B, T, F)) > 0.7).astype(np.float32)
+    w = comp.w().cpu().numpy().reshape(C, Cd)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    feat = (torch.tensor(fmap, dtype=torch.float64) @ wt).reshape(B, T, F * Cd)
+    # the oracle's two_step_inputs on torch tensors
+    x = torch.zeros((B, 2 * T - 1, 1 + F * Cd + F), dtype=torch.float64)
+    x[:, 0, 1:1 + F * Cd] = feat[:, 0]
+    x[:, 0, 1 + F * Cd:] = torch.tensor(gts[:, 0], dtype=torch.float64)
+    for t in range(1, T):
+        x[:, 2 * t - 1, 1:1 + F * Cd] = feat[:, t]
+        x[:, 2 * t, 0] = 1
+    np.testing.assert_allclose(x.detach().numpy(), O.two_step_inputs(feat.detach().numpy(), gts[:, 0].astype(np.float64)), atol=0)
+    logits, _ = OT.loop(cfg, pt, x)
+    q = torch.softmax(torch.tensor(O.two_step_labels(gts.astype(np.float64))), dim=2)
+    loss_ref = -(q * torch.log_softmax(logits, dim=2)).sum() / ((2 * T - 1) * B)
+    loss_ref.backward()
+    loss, _p = trk.loss_and_grads(torch.from_numpy(fmap).to(cuda), torch.from_numpy(gts).to(cuda))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.cpu()), float(loss_ref.detach()), rtol=1e-4)
+    gw = comp.grad.t().cpu().numpy()                                    # [C, Cd]
+    ref = wt.grad.numpy()
+    assert np.max(np.abs(gw - ref)) / np.max(np.abs(ref)) < 3e-3
+    got = trk.cell.params.to_tf(grad=True)
+    gmax = max(float(np.abs(pt[k].grad.numpy()).max()) for k in sd)
+    for k in sorted(sd):
+        r = pt[k].grad.numpy()
+        assert np.max(np.abs(got[k].numpy() - r)) / max(np.max(np.abs(r)), 1e-3 * gmax) < 3e-3, k
