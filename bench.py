@@ -95,7 +95,7 @@ def host_cpu_info():
             "logical_cpus": os.cpu_count()}
 
 
-def _cpu_sample(ws, threads, n_vgg_frames, T, O, OT):
+def _cpu_sample(ws, threads, n_vgg_frames, T, O, OT, model="ntm", dnc_shape=(256, 64)):
     torch.set_num_threads(threads)
     rng = np.random.default_rng(42)
     frames = (rng.uniform(0, 255, size=(n_vgg_frames, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)
@@ -103,20 +103,33 @@ def _cpu_sample(ws, threads, n_vgg_frames, T, O, OT):
     t0 = time.perf_counter()
     OT.vgg16_conv43(frames, ws)
     t_vgg = (time.perf_counter() - t0) / n_vgg_frames
-    cfg = O.NTMConfig(514, 2, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=200,
-                      controller_num_layers=1, write_head_size=1, read_head_size=4)
-    params = O.init_params(cfg, rng)
     feats = np.maximum(rng.standard_normal((1, T, 64, 512)), 0).astype(np.float32)
     x = O.serialize_inputs(feats, rng.uniform(0, 1, size=(1, T, 64)).astype(np.float32))
     offs = rng.uniform(-.5, .5, size=(1, T, 2)).astype(np.float32)
-    t0 = time.perf_counter()
-    OT.loss_and_grads(cfg, params, x, offs, dtype=torch.float32)
-    t_ntm = time.perf_counter() - t0
-    log("cpu_baseline: %d thread(s): VGG %.3f s/frame, NTM fwd+BPTT %.2f s/sequence" % (threads, t_vgg, t_ntm))
+    if model == "dnc":
+        # the DNC core of the benchmarked configuration: forward + BPTT of one sequence on the torch-CPU autograd restatement
+        from oracle import dnc_oracle as D
+        from oracle import dnc_oracle_torch as DTo
+        cfg = D.DNCConfig(514, 2, memory_size=dnc_shape[0], word_size=dnc_shape[1], num_reads=4, num_writes=1, hidden_size=200, clip_value=20)
+        params = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in D.init_params(cfg, rng).items()}
+        xt = torch.tensor(np.ascontiguousarray(np.transpose(x, (1, 0, 2))), dtype=torch.float32)          # time-major
+        t0 = time.perf_counter()
+        ys, _ = DTo.run_model(cfg, params, xt)
+        pred = torch.tanh(ys[65:].reshape(T - 1, 65, 1, 2)[:, 64])
+        (0.5 * ((pred - torch.tensor(offs[:, 1:].transpose(1, 0, 2))) ** 2).sum()).backward()
+        t_ntm = time.perf_counter() - t0
+    else:
+        cfg = O.NTMConfig(514, 2, mem_size=128, mem_dim=20, shift_range=1, controller_hidden_size=200,
+                          controller_num_layers=1, write_head_size=1, read_head_size=4)
+        params = O.init_params(cfg, rng)
+        t0 = time.perf_counter()
+        OT.loss_and_grads(cfg, params, x, offs, dtype=torch.float32)
+        t_ntm = time.perf_counter() - t0
+    log("cpu_baseline: %d thread(s): VGG %.3f s/frame, %s fwd+BPTT %.2f s/sequence" % (threads, t_vgg, model.upper(), t_ntm))
     return T / (T * t_vgg + t_ntm), t_vgg, t_ntm
 
 
-def cpu_baseline(ws, n_vgg_frames=8, T=20):
+def cpu_baseline(ws, n_vgg_frames=8, T=20, model="ntm", dnc_shape=(256, 64)):
     """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample of the same
     workload: VGG trunk on `n_vgg_frames` frames (torch-CPU conv2d, the op granularity TF-CPU would run) + NTM
     forward + BPTT of ONE sequence of T frames (torch-CPU autograd restatement), combined as frames/s of one
@@ -128,13 +141,13 @@ def cpu_baseline(ws, n_vgg_frames=8, T=20):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))      # the box's CPU share for one GPU is 16 cores
-    fps, t_vgg, t_ntm = _cpu_sample(ws, cores, n_vgg_frames, T, O, OT)
-    fps1, t_vgg1, t_ntm1 = _cpu_sample(ws, 1, 2, T, O, OT)
+    fps, t_vgg, t_ntm = _cpu_sample(ws, cores, n_vgg_frames, T, O, OT, model, dnc_shape)
+    fps1, t_vgg1, t_ntm1 = _cpu_sample(ws, 1, 2, T, O, OT, model, dnc_shape)
     torch.set_num_threads(cores)
     out = {"value": round(fps, 3), "unit": "frames/sec", "cores": cores, "kind": "port",
-           "sample": "VGG conv1_1..conv4_3 on %d frames (torch-CPU conv2d, %.3f s/frame) + NTM fwd+BPTT of 1 "
+           "sample": "VGG conv1_1..conv4_3 on %d frames (torch-CPU conv2d, %.3f s/frame) + %s fwd+BPTT of 1 "
                      "sequence x %d frames (torch-CPU autograd restatement, %.2f s); frames/s of one sequence"
-                     % (n_vgg_frames, t_vgg, T, t_ntm),
+                     % (n_vgg_frames, t_vgg, "NTM" if model == "ntm" else "DNC(%dx%d)" % dnc_shape, T, t_ntm),
            "single_thread": {"value": round(fps1, 3), "unit": "frames/sec", "vgg_s_per_frame": round(t_vgg1, 3),
                              "ntm_s_per_sequence": round(t_ntm1, 2)}}
     out.update(host_cpu_info())
@@ -390,7 +403,9 @@ def main():
         }
         out["memory_step"], out["memory_step_bptt"] = memory_step_probe(trk, args.model, gts0, offs, B, T)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ws)
+            # the DNC restatement costs ~15 ms per step on the host: a 4-frame sequence keeps the sample inside its time budget
+            out["cpu_baseline"] = cpu_baseline(ws, T=20 if args.model == "ntm" else 4, model=args.model,
+                                               dnc_shape=(args.mem_size or 256, args.mem_dim or 64))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
