@@ -524,8 +524,9 @@ extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_p
     NTK_REQUIRE(cin >= 16 && (cin % 16) == 0 && cout >= 64 && (cout % 64) == 0, NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_wino43_f32: cin=%d (multiple of 16: the K loop takes two 8-channel steps per trip) "
                 "cout=%d (multiple of 64)", cin, cout);
-    NTK_REQUIRE((unsigned long long)2 * H * W * cin * sizeof(float) < 0xffffffffull, NTK_ERR_UNSUPPORTED,
-                "ntk_vgg_conv3x3_relu_wino43_f32: two frames of %d x %d x %d floats exceed the 32-bit staging offsets", H, W, cin);
+    NTK_REQUIRE((unsigned long long)2 * H * W * cin * sizeof(float) <= 0x40000000ull, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino43_f32: two frames of %d x %d x %d floats exceed the 1 GiB window of the staging buffer resource",
+                H, W, cin);
     Wino43Args a;
     a.in = in; a.U = u_packed; a.bias = bias; a.out = out;
     a.frames = frames; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;

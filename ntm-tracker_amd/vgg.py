@@ -94,7 +94,7 @@ def wino43_supported(cin, cout, H, W, frames=1):
     """Shapes the fused Winograd F(4x4,3x3) kernel takes."""
     nCB = cout // 64
     return (cin % 16 == 0 and cout % 64 == 0 and nCB >= 1 and (8 % nCB == 0 if nCB <= 8 else nCB % 8 == 0)
-            and H % 4 == 0 and W % 4 == 0 and 2 * H * W * cin * 4 < 0xffffffff)
+            and H % 4 == 0 and W % 4 == 0 and 2 * H * W * cin * 4 <= 0x40000000)
 
 
 def pack_weights_wino43(w_hwio):
