@@ -402,8 +402,8 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* sZ = s_mem;                                   // [36][32 tiles][32 channels]
     const int col = lane & 31;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm-form MFMAs' results are complete before they are read
-#pragma unroll 1
-    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {                      // unrolled: the accumulator selection below is static
         __syncthreads();
         W43_STAMP(19);
 #pragma unroll
