@@ -299,8 +299,30 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // U request precedes the K step's patch requests (HBM latency), which then only have to be back two groups later,
         // when they are stored.  A operand: ONE set, re-read for the next group right after a group's last MFMA has issued.
         constexpr bool DONOR = ROLE <= 1;                               // gives (plane 8, half 1) to wave ROLE + 2
-        f32x4 Bq[2][3][2], Aq[3], Bx[2], Ax;
-        Bx[0] = Bx[1] = Ax = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The A sets alternate by K-step parity: the LAST twelve MFMAs of a K step (group 2, K pairs 2-3) are issued at the top
+        // of the NEXT one, right after the barrier and after that step's first A operands have been requested -- their LDS
+        // latency hides behind MFMAs whose operands are already in registers.
+        f32x4 Bq[2][3][2], As[2][3], Bx[2], Axs[2];
+        Bx[0] = Bx[1] = Axs[0] = Axs[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // MFMAs of plane group g, K pairs 2 half, 2 half + 1, operands from A set `as` and B set `bs`
+        auto mfma_half = [&](auto g_c, auto half_c, auto as_c, auto bs_c) {
+            constexpr int g = decltype(g_c)::value, half = decltype(half_c)::value, as = decltype(as_c)::value, bs = decltype(bs_c)::value;
+#pragma unroll
+            for (int q = 2 * half; q < 2 * half + 2; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (3 * g + pl < 8) {
+                        acc[3 * g + pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[as][pl][q], Bq[bs][pl][0][q], acc[3 * g + pl][0], 0, 0, 0);
+                        acc[3 * g + pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[as][pl][q], Bq[bs][pl][1][q], acc[3 * g + pl][1], 0, 0, 0);
+                    } else {
+                        w43_mfma_v(accv[0], As[as][pl][q], Bq[bs][pl][0][q]);
+                        if constexpr (!DONOR) {
+                            w43_mfma_v(accv[1], As[as][pl][q], Bq[bs][pl][1][q]);
+                            w43_mfma_v(accx, Axs[as][q], Bx[bs][q]);
+                        }
+                    }
+                }
+        };
         const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.U + (size_t)cb * n8 * 18432), 0, (int)((size_t)n8 * 18432 * sizeof(float)), 0x00020000);
         const unsigned ulane = (unsigned)lane * 16u + (unsigned)ROLE * 18432u;          // bytes: + this wave's 4608 floats
@@ -330,8 +352,14 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float* rnext = s_raw + (PAR ^ 1) * RAWF;
             float* vnext = s_V + (PAR ^ 1) * VF;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + pl * 256);
+            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) As[PAR][pl] = *reinterpret_cast<const f32x4*>(vcur + pl * 256);
             if constexpr (!(W43_ABL & 2)) tr_reads(rnext, 0);
+            // the previous K step's last twelve MFMAs (its group 2 sits in A set PAR ^ 1 and B set PAR ^ 1)
+            if (PAR == 1 || c8 > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_half(ic<2>{}, ic<1>{}, ic<PAR ^ 1>{}, ic<PAR ^ 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const int bs = (PAR + g) & 1;
@@ -344,21 +372,13 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 2 * half; q < 2 * half + 2; ++q)
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) {
-                            if (3 * g + pl < 8) {
-                                acc[3 * g + pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[bs][pl][0][q], acc[3 * g + pl][0], 0, 0, 0);
-                                acc[3 * g + pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[pl][q], Bq[bs][pl][1][q], acc[3 * g + pl][1], 0, 0, 0);
-                            } else {
-                                w43_mfma_v(accv[0], Aq[pl][q], Bq[bs][pl][0][q]);
-                                if constexpr (!DONOR) {
-                                    w43_mfma_v(accv[1], Aq[pl][q], Bq[bs][pl][1][q]);
-                                    w43_mfma_v(accx, Ax[q], Bx[bs][q]);
-                                }
-                            }
-                        }
+                    if (!(g == 2 && half == 1)) {                   // (2, 1) is issued at the top of the next K step
+                        if (g == 0 && half == 0) mfma_half(ic<0>{}, ic<0>{}, ic<PAR>{}, ic<PAR>{});
+                        if (g == 0 && half == 1) mfma_half(ic<0>{}, ic<1>{}, ic<PAR>{}, ic<PAR>{});
+                        if (g == 1 && half == 0) mfma_half(ic<1>{}, ic<0>{}, ic<PAR>{}, ic<PAR ^ 1>{});
+                        if (g == 1 && half == 1) mfma_half(ic<1>{}, ic<1>{}, ic<PAR>{}, ic<PAR ^ 1>{});
+                        if (g == 2 && half == 0) mfma_half(ic<2>{}, ic<0>{}, ic<PAR>{}, ic<PAR>{});
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     W43_STAMP(2 + 4 * g + 2 * half);
                     if (half == 0) {
@@ -370,8 +390,8 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     } else {
                         if (g < 2) {
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) Aq[pl] = *reinterpret_cast<const f32x4*>(vcur + (3 * (g + 1) + pl) * 256);
-                            if constexpr (!DONOR && !(W43_ABL & 16)) if (g == 1) Ax = *reinterpret_cast<const f32x4*>(s_V + PAR * VF + vxbase);
+                            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) As[PAR][pl] = *reinterpret_cast<const f32x4*>(vcur + (3 * (g + 1) + pl) * 256);
+                            if constexpr (!DONOR && !(W43_ABL & 16)) if (g == 1) Axs[PAR] = *reinterpret_cast<const f32x4*>(s_V + PAR * VF + vxbase);
                         } else {
                             if constexpr (!(W43_ABL & 4)) stage_store(PAR);
                         }
@@ -389,6 +409,7 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             k_step(c8, ic<0>{});
             k_step(c8 + 1, ic<1>{});
         }
+        mfma_half(ic<2>{}, ic<1>{}, ic<1>{}, ic<1>{});             // the last K step's (odd parity: n8 is even) deferred MFMAs
     };
     if (wave == 0) k_loop(ic<0>{});
     else if (wave == 1) k_loop(ic<1>{});
@@ -401,7 +422,9 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
     float* sZ = s_mem;                                   // [36][32 tiles][32 channels]
     const int col = lane & 31;
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm-form MFMAs' results are complete before they are read
+    // the asm-form MFMAs (the last instructions of the K loop) have written their results before anything reads them: a
+    // 16-pass MFMA needs 18 passes of distance to a dependent VALU / LDS instruction
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {                      // unrolled: the accumulator selection below is static
         __syncthreads();
