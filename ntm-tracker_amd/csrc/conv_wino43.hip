@@ -360,6 +360,10 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 mfma_half(ic<2>{}, ic<1>{}, ic<PAR ^ 1>{}, ic<PAR ^ 1>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // A set PAR ^ 1 is free now: group 1's operands are requested a whole group ahead (the groups alternate between
+            // the two sets: 0 -> PAR, 1 -> PAR ^ 1, 2 -> PAR, where the next K step's deferred MFMAs expect them)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) As[PAR ^ 1][pl] = *reinterpret_cast<const f32x4*>(vcur + (3 + pl) * 256);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const int bs = (PAR + g) & 1;
@@ -375,8 +379,8 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (!(g == 2 && half == 1)) {                   // (2, 1) is issued at the top of the next K step
                         if (g == 0 && half == 0) mfma_half(ic<0>{}, ic<0>{}, ic<PAR>{}, ic<PAR>{});
                         if (g == 0 && half == 1) mfma_half(ic<0>{}, ic<1>{}, ic<PAR>{}, ic<PAR>{});
-                        if (g == 1 && half == 0) mfma_half(ic<1>{}, ic<0>{}, ic<PAR>{}, ic<PAR ^ 1>{});
-                        if (g == 1 && half == 1) mfma_half(ic<1>{}, ic<1>{}, ic<PAR>{}, ic<PAR ^ 1>{});
+                        if (g == 1 && half == 0) mfma_half(ic<1>{}, ic<0>{}, ic<PAR ^ 1>{}, ic<PAR ^ 1>{});
+                        if (g == 1 && half == 1) mfma_half(ic<1>{}, ic<1>{}, ic<PAR ^ 1>{}, ic<PAR ^ 1>{});
                         if (g == 2 && half == 0) mfma_half(ic<2>{}, ic<0>{}, ic<PAR>{}, ic<PAR>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -388,11 +392,11 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         }
                         W43_STAMP(3 + 4 * g);
                     } else {
-                        if (g < 2) {
+                        if (g == 0) {                              // group 0 has issued: its set takes group 2's operands
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) As[PAR][pl] = *reinterpret_cast<const f32x4*>(vcur + (3 * (g + 1) + pl) * 256);
-                            if constexpr (!DONOR && !(W43_ABL & 16)) if (g == 1) Axs[PAR] = *reinterpret_cast<const f32x4*>(s_V + PAR * VF + vxbase);
-                        } else {
+                            for (int pl = 0; pl < 3; ++pl) if constexpr (!(W43_ABL & 16)) As[PAR][pl] = *reinterpret_cast<const f32x4*>(vcur + (6 + pl) * 256);
+                            if constexpr (!DONOR && !(W43_ABL & 16)) Axs[PAR] = *reinterpret_cast<const f32x4*>(s_V + PAR * VF + vxbase);
+                        } else if (g == 2) {
                             if constexpr (!(W43_ABL & 4)) stage_store(PAR);
                         }
                         if constexpr (!(W43_ABL & 2)) {
