@@ -213,6 +213,9 @@ def memory_step_probe(trk, model, gts0, offs, B, T):
         note = ("serialise + input projection + persistent cluster kernel: link rows and memory LDS resident, two mailbox hand-offs per step"
                 if k > 1 else "serialise + input projection + persistent sequence kernel, one workgroup per sequence; link and memory L2 resident")
         tnote = "PMC, profiles/r02_dnc_cluster_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE)"
+        if k > 1:
+            pl = c.cluster_placement()
+            note += "; clusters on one XCD handing off through that XCD's L2 (forward, BPTT launch): " + ", ".join("%d of %d" % x for x in pl)
 
     def entry(kernel, t_ms, tr):
         gbps = per_step * B * S / (t_ms * 1e-3) / 1e9

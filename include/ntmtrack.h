@@ -241,9 +241,13 @@ int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, f
  * num_writes != 1, memory_size not a multiple of 64, ...) and the workspace size in bytes.  The workspace is
  * caller-owned device memory, 16-byte aligned, private to one launch at a time; its control words are re-zeroed by
  * every launch.  ntk_dnc_cluster_status synchronises `stream` and reports whether a hand-off of the last launch on
- * that workspace timed out (every in-kernel spin is bounded; a launch that could not make progress aborts itself). */
+ * that workspace timed out (every in-kernel spin is bounded; a launch that could not make progress aborts itself).
+ * ntk_dnc_cluster_placement synchronises `stream` and reports how many of the B clusters of the last launch on that
+ * workspace found all their k workgroups on one XCD and therefore ran the same-XCD form of the hand-offs (plain stores
+ * kept in that XCD's L2; the others ran the write-through form: a speed difference only, csrc/dnc_cluster.h). */
 int ntk_dnc_cluster_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes);
 int ntk_dnc_cluster_status(const void* workspace, int B, int k, void* stream);
+int ntk_dnc_cluster_placement(const void* workspace, int B, int k, int* same_xcd_clusters, void* stream);
 int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value, int k,
                         const float* xproj, const float* Wr, const float* Wi, const float* Wy,
                         float* mem, float* link, float* usage, float* rw, float* ww, float* prec,

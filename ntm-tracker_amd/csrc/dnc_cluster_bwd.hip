@@ -113,6 +113,7 @@ struct DncClBwdArgs {
     const float* dout;
     float* gM; float* gL; float* dgates; float* dxi; float* dypre; float* gcarry;
     float* mbox; unsigned* flags; unsigned* err;
+    unsigned* xcc;         // [B][k] handshake words of cl_same_xcd (control block)
 };
 
 __device__ __forceinline__ float cl_dot4(const f32x4& x, const f32x4& y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3]; }
@@ -201,6 +202,14 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         }
     }
     __syncthreads();
+    // same-XCD fast form of the hand-offs (dnc_cluster.h): decided per cluster by a handshake, never assumed
+    bool plain = false;
+    if (a0.xcd_local) {
+        int* const sw = reinterpret_cast<int*>(smem + (FIX ? kDncClFixBwdLds.SC : a0.lds.SC)) + 121;
+        const int same = cl_same_xcd(a0.xcc + (size_t)b * kk0, g, kk0, a0.err, sw - 1, sw, t_start, tid0);
+        if (same < 0) return;
+        plain = __builtin_amdgcn_readfirstlane(same) != 0;
+    }
 #ifdef NTK_CL_PROF
     unsigned long long prof_acc[20] = {0}, prof_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                             sGL4[ph] = gn;
                         }
                         rowWW = wave_sum(rowWW);
-                        if (lane == 0) cl_store(slot + R * NR + r, rowWW);
+                        if (lane == 0) cl_store(slot + R * NR + r, rowWW, plain);
                     }
                 }
             }
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < CW; ++w) s += sPart[(w * 2 + which) * N + c];
-                cl_store(slot + (R + 1) * NR + R * N + idx, s);
+                cl_store(slot + (R + 1) * NR + R * N + idx, s, plain);
             }
             __syncthreads();
         CLB_STAMP(6);
@@ -615,7 +624,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     }
                     acc0 += acc1;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) if (v < R) cl_store(slot + (R + 1) * NR + v * N + c, acc0[v]);
+                    for (int v = 0; v < 4; ++v) if (v < R) cl_store(slot + (R + 1) * NR + v * N + c, acc0[v], plain);
                 } else {
                     const int rg = job - strips;
                     const int par2 = lane >> 5;
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                 const int i = cl_div(idx, C.mg_NR), r = idx - i * NR;
                 float f = 0.f;
                 for (int qq = 0; qq < 2 * strips; ++qq) f += sPart[(qq * NRp + r) * 4 + i];
-                cl_store(slot + idx, f);
+                cl_store(slot + idx, f, plain);
             }
             if (NR <= 4 * CW && colok) {          // L_{t-1} rows (still in registers) become the next iteration's L_t tile
 #pragma unroll
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
                     if (r < NR) sLt4[r * N4 + (lane ^ (r & 7))] = lpv[u];
                 }
             }
-            cl_publish(fl0 + g, epoch, tid);
+            cl_publish(fl0 + g, epoch, tid, plain);
         }
         CLB_STAMP(7);
         if (!cl_wait(fl0, epoch, k, a.err, sAbort, t_start, tid)) return;
@@ -984,9 +993,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
             for (int kk = tid; kk < Q.ldkT; kk += CT) {
                 float s = 0.f;
                 for (int sl = 0; sl < Q.nslZ; ++sl) s += sPart[sl * Q.ldkT + kk];
-                cl_store(slot + kk, s);
+                cl_store(slot + kk, s, plain);
             }
-            cl_publish(fl1 + g, epoch, tid);
+            cl_publish(fl1 + g, epoch, tid, plain);
         }
         CLB_STAMP(15);
         if (!cl_wait(fl1, epoch, k, a.err, sAbort, t_start, tid)) return;
@@ -1047,7 +1056,6 @@ extern "C" int ntk_dnc_cluster_bwd_prof(unsigned long long* out20) {
     return hipMemcpyFromSymbol(out20, HIP_SYMBOL(g_clb_prof), 20 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
 }
 #endif
-static size_t dnc_cluster_ctrl_bytes(int B, int k) { return (((size_t)B * 2 * k + 1) * sizeof(unsigned) + 255) & ~(size_t)255; }
 
 // cluster size for the backward pass (0 = outside its range): the forward constraints plus N <= 256 (d(memory) is
 // register resident: one row of 8 per 16-lane group), W <= 64, hid % 4 == 0
@@ -1127,6 +1135,7 @@ extern "C" int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, in
     const size_t ctrl = dnc_cluster_ctrl_bytes(B, k);
     a.flags = reinterpret_cast<unsigned*>(workspace);
     a.err = a.flags + (size_t)B * 2 * k;
+    a.xcc = a.err + 1;
     a.mbox = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ctrl);
     {
         static NtkLdsAttrCache lds_cache;

@@ -20,6 +20,7 @@
 //   forward   D[row][head]  += L[row][col] * rw_prev[head][col]      block = 4 rows,    one link column per block
 // (exact fp32 FMA chains, k-ordered: same numerics as a scalar loop).
 #include "dnc_cluster.h"
+#include <vector>
 
 // Diagnostic build only (-DNTK_CL_PROF): workgroup 0 accumulates s_memtime deltas per phase (its wave 0, lane 0) into
 // g_cl_prof; ntk_dnc_cluster_prof() copies them out.  The stamps serialise the phases: read SHARES, not totals.
@@ -88,6 +89,7 @@ struct DncClFwdArgs {
     float* rec_ww; float* rec_rw; float* rec_cw; float* rec_cr; float* rec_al; float* rec_p; float* rec_fwd;
     float* rec_bwd; float* rec_M; float* rec_L; float* rec_ypre;
     float* mbox; unsigned* flags; unsigned* err;
+    unsigned* xcc;         // [B][k] handshake words of cl_same_xcd (control block)
 };
 
 __device__ __forceinline__ void cl_softmax_row(float* r, int N, int lane) {      // one wave, in place
@@ -176,7 +178,36 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
         for (int i = tid0; i < (1 + R) * W; i += CT) sK[i] = 0.f;
     }
     __syncthreads();
+    // same-XCD fast form of the hand-offs (dnc_cluster.h): decided per cluster by a handshake, never assumed
+    bool plain = false;
+    if (a0.xcd_local) {
+        int* const sw = reinterpret_cast<int*>(smem + (FIX ? kDncClFixFwdLds.SC : a0.lds.SC)) + 33;
+        const int same = cl_same_xcd(a0.xcc + (size_t)b * kk0, g, kk0, a0.err, sw - 1, sw, t_start, tid0);
+        if (same < 0) return;
+        plain = __builtin_amdgcn_readfirstlane(same) != 0;
+    }
 
+    // FIX: the slice of Wr a thread multiplies in P1 (own unit j x K-slice ks: kperG rows of one float4 gate column) never
+    // changes -- it lives in registers for the whole sequence (23 x 4 of the 256 a thread has at two waves per SIMD)
+    // instead of being streamed from L2 every step (182 KB per workgroup and step); the step's input projection row is
+    // requested one step ahead.  Same products in the same order as ntk_stream_matvec: results are unchanged.
+    constexpr int KPG = kDncClusterFixCfg.kperG;
+    f32x4 wres[FIX ? KPG : 1];
+    f32x4 xg_bias = {0.f, 0.f, 0.f, 0.f}, xp_next = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FIX) {
+        constexpr DncClusterCfg C = kDncClusterFixCfg;
+        const f32x4* Wr4 = reinterpret_cast<const f32x4*>(a0.Wr);
+        const int u0 = min(C.hid, g * C.upk), nU = min(C.hid, u0 + C.upk) - u0;
+        const int ks = cl_div(tid0, C.mg_upk), j = tid0 - ks * C.upk, k0 = ks * KPG;
+        const bool act = tid0 < C.ksl * C.upk && j < nU;
+#pragma unroll
+        for (int q = 0; q < KPG; ++q)
+            wres[q] = (act && k0 + q < C.K) ? Wr4[(size_t)(k0 + q) * C.hid + u0 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid0 < nU) {
+            xg_bias = Wr4[(size_t)C.K * C.hid + u0 + tid0];
+            xp_next = reinterpret_cast<const f32x4*>(a0.xproj)[(size_t)b * S * C.hid + u0 + tid0];
+        }
+    }
 #ifdef NTK_CL_PROF
     unsigned long long prof_acc[16] = {0}, prof_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -212,13 +243,19 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
 
         // ------------------------------------------------------------ P1: LSTM gates of the own hidden units
         f32x4 xg = {0.f, 0.f, 0.f, 0.f};
-        if (tid < nU) xg = reinterpret_cast<const f32x4*>(a.xproj)[bt * hid + u0 + tid] + Wr4[(size_t)K * hid + u0 + tid];
+        if constexpr (FIX) xg = xp_next + xg_bias;
+        else if (tid < nU) xg = reinterpret_cast<const f32x4*>(a.xproj)[bt * hid + u0 + tid] + Wr4[(size_t)K * hid + u0 + tid];
         if (rec && g == 0) for (int i = tid; i < C.ldz; i += CT) a.rec_z[bt * C.ldz + i] = (i < K) ? sZ[i] : (i == K ? 1.f : 0.f);
         if (tid < ksl * upk) {
             const int ks = cl_div(tid, C.mg_upk), j = tid - ks * upk;
             const int k0 = ks * kperG, k1 = min(K, k0 + kperG);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (j < nU && k0 < k1) acc = ntk_stream_matvec<4>(Wr4 + u0 + j, hid, sZ, k0, k1, K - 1);
+            if constexpr (FIX) {
+#pragma unroll
+                for (int q = 0; q < KPG; ++q) acc += ((k0 + q < k1) ? sZ[k0 + q] : 0.f) * wres[q];
+            } else {
+                if (j < nU && k0 < k1) acc = ntk_stream_matvec<4>(Wr4 + u0 + j, hid, sZ, k0, k1, K - 1);
+            }
             sPart4[ks * upk + j] = acc;
         }
         __syncthreads();
@@ -255,13 +292,13 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
         CL_STAMP(1);
         {   // publish exchange 0: [h of the own units | interface partial]
             float* slot = mb0 + ((size_t)par * k + g) * slot0;
-            if (tid < nU) cl_store(slot + tid, sZ[RWd + u0 + tid]);
+            if (tid < nU) cl_store(slot + tid, sZ[RWd + u0 + tid], plain);
             for (int c = tid; c < IP; c += CT) {
                 float v = 0.f;
                 for (int us = 0; us < nslI; ++us) v += sPart[us * IP + c];
-                cl_store(slot + upkp + c, v);
+                cl_store(slot + upkp + c, v, plain);
             }
-            cl_publish(fl0 + g, epoch, tid);
+            cl_publish(fl0 + g, epoch, tid, plain);
         }
         // y_{t-1} = clip([h_{t-1} ; reads_{t-1}] Wy + by) (dnc.py:118-122) does not feed the recurrence: workgroup 0 computes it
         // HERE, in the shadow of the hand-off (its wave 0 polls, waves 1.. have nothing else to do), not on the step's
@@ -303,6 +340,9 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
                 if (c >= C.oKw && c < C.oBw) sK[c - C.oKw] = r;
                 else if (c >= C.oKr && c < C.oBr) sK[W + (c - C.oKr)] = r;
             }
+        }
+        if constexpr (FIX) {   // the next step's input projection row (HBM): requested here, used at the top of the next step
+            if (tid < nU && t + 1 < S) xp_next = reinterpret_cast<const f32x4*>(a.xproj)[(bt + 1) * hid + u0 + tid];
         }
         __syncthreads();
         CL_STAMP(4);
@@ -519,7 +559,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
                 }
                 acc0 += acc1;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) if (v < R) cl_store(slot1p + R * NR + v * N + c, acc0[v]);
+                for (int v = 0; v < 4; ++v) if (v < R) cl_store(slot1p + R * NR + v * N + c, acc0[v], plain);
             } else {                                         // forward: row sums of the own rows over a 64-column range
                 const int rg = job - strips;
                 const int par2 = lane >> 5;
@@ -553,7 +593,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
             const int i = cl_div(idx, C.mg_NR), r = idx - i * NR;
             float f = 0.f;
             for (int q = 0; q < 2 * strips; ++q) f += sPart[(q * NRp + r) * 4 + i];
-            cl_store(slot1p + idx, f);
+            cl_store(slot1p + idx, f, plain);
         }
         if (wave >= CW - R) cl_softmax_row(sCR + (wave - (CW - R)) * N, N, lane);     // read content weights
         if (wave == CW - R - 1) {                                                     // sum of the write weights (precedence)
@@ -562,7 +602,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_fwd_kernel(DncClFwdArgs a0) {
             s = wave_sum(s);
             if (lane == 0) sSC[0] = s;
         }
-        cl_publish(fl1 + g, epoch, tid);
+        cl_publish(fl1 + g, epoch, tid, plain);
         CL_STAMP(11);
         if (!cl_wait(fl1, epoch, k, a.err, sAbort, t_start, tid)) return;
         CL_STAMP(12);
@@ -721,8 +761,6 @@ static int dnc_cluster_pick(int B, int N, int W, int R, int Wn, int hid, int O, 
     return 0;
 }
 
-// control block (flags + error word) first, padded to 256 bytes, then the mailbox
-static size_t dnc_cluster_ctrl_bytes(int B, int k) { return (((size_t)B * 2 * k + 1) * sizeof(unsigned) + 255) & ~(size_t)255; }
 
 extern "C" int ntk_dnc_cluster_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k,
                                     size_t* workspace_bytes) {
@@ -748,6 +786,23 @@ extern "C" int ntk_dnc_cluster_status(const void* workspace, int B, int k, void*
     if (rc == hipSuccess) rc = hipStreamSynchronize((hipStream_t)stream);
     NTK_REQUIRE(rc == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_status: %s", hipGetErrorString(rc));
     NTK_REQUIRE(e == 0, NTK_ERR_HIP, "ntk_dnc_cluster_status: a cluster hand-off timed out (the launch was aborted; its outputs are invalid)");
+    return NTK_OK;
+}
+
+extern "C" int ntk_dnc_cluster_placement(const void* workspace, int B, int k, int* same_xcd_clusters, void* stream) {
+    NTK_REQUIRE(workspace && same_xcd_clusters && B > 0 && k > 0 && k <= 64, NTK_ERR_BAD_PTR, "ntk_dnc_cluster_placement: bad arguments");
+    std::vector<unsigned> w((size_t)B * k);
+    const unsigned* xcc = reinterpret_cast<const unsigned*>(workspace) + (size_t)B * 2 * k + 1;
+    hipError_t rc = hipMemcpyAsync(w.data(), xcc, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (rc == hipSuccess) rc = hipStreamSynchronize((hipStream_t)stream);
+    NTK_REQUIRE(rc == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_placement: %s", hipGetErrorString(rc));
+    int n = 0;
+    for (int b = 0; b < B; ++b) {
+        bool same = w[(size_t)b * k] != 0;          // 0 = no handshake ran (batch not a multiple of 8)
+        for (int g = 1; g < k; ++g) same = same && w[(size_t)b * k + g] == w[(size_t)b * k];
+        n += same ? 1 : 0;
+    }
+    *same_xcd_clusters = n;
     return NTK_OK;
 }
 
@@ -789,6 +844,7 @@ extern "C" int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, in
     const size_t ctrl = dnc_cluster_ctrl_bytes(B, k);
     a.flags = reinterpret_cast<unsigned*>(workspace);
     a.err = a.flags + (size_t)B * 2 * k;
+    a.xcc = a.err + 1;
     a.mbox = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ctrl);
     {
         static NtkLdsAttrCache lds_cache;

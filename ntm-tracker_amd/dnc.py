@@ -332,6 +332,18 @@ class DNC(object):
             if c is not None and c[1] > 1:
                 _lib.check(_lib.lib().ntk_dnc_cluster_status(_P(c[2]), c[0][0], c[1], _lib.stream()), "ntk_dnc_cluster_status")
 
+    def cluster_placement(self):
+        """(clusters that ran the same-XCD form of the hand-offs, clusters) of the last forward / BPTT cluster launches;
+        a speed diagnostic only (csrc/dnc_cluster.h).  Synchronises."""
+        out = []
+        for c in (self._cluster, self._cluster_b):
+            if c is not None and c[1] > 1:
+                n = ctypes.c_int(0)
+                _lib.check(_lib.lib().ntk_dnc_cluster_placement(_P(c[2]), c[0][0], c[1], ctypes.byref(n), _lib.stream()),
+                           "ntk_dnc_cluster_placement")
+                out.append((n.value, c[0][0]))
+        return out
+
     def _launch_fwd(self, xproj, B, S, st, rec):
         """One sequence-kernel launch over contiguous xproj [B*S, 4*hid] starting from state `st` (not modified):
         the cluster kernel (k CUs per sequence) when the shape allows, else one workgroup per sequence."""

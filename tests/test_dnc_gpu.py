@@ -349,6 +349,10 @@ CLUSTER_CASES = [
     ("small_64x16", 64, 16, 2, 24, 7, 3, (2, 4, 8)),
     ("r1_128x32", 128, 32, 1, 40, 5, 1, (4,)),
     ("r3_odd_hidden", 128, 20, 3, 36, 5, 2, (8,)),
+    # batches that are a multiple of 8: the clusters are laid out one XCD each and, where the launch-time handshake
+    # confirms it, hand off through plain stores kept in that XCD's L2 (csrc/dnc_cluster.h)
+    ("c3_shape_b8_same_xcd", 256, 64, 4, 200, 6, 8, (8,)),
+    ("small_64x16_b16_same_xcd", 64, 16, 2, 24, 7, 16, (4, 8)),
 ]
 
 
@@ -422,6 +426,9 @@ def test_dnc_cluster_forward_full_length_is_deterministic(cuda):
     o1, s1 = core.run_sequence(x)
     core.check_cluster()
     assert core.last_cluster_k == 8
+    (same, total), = core.cluster_placement()
+    print("clusters that ran the same-XCD hand-off form: %d of %d" % (same, total))
+    assert total == B and 0 <= same <= B          # placement is observed, never promised: a diagnostic, not a requirement
     o2, s2 = core.run_sequence(x)
     core.check_cluster()
     assert torch.equal(o1, o2) and torch.equal(s1.access_state.linkage.link, s2.access_state.linkage.link)
