@@ -65,6 +65,9 @@ struct DncFwdArgs {
     float* rec_ypre;      // [B,S,O]    output before clipping
 };
 
+constexpr int DNC_PFM = 4;    // rows of M a lane group requests per batch
+constexpr int DNC_PFL = 1;    // rows of the link a wave requests per batch (more spill at 128 VGPRs)
+
 struct DncLds {
     int part, Z, C, I, U, RW, WW, P, CW, CR, AL, FWD, BWD, SC, total;
 };
@@ -78,8 +81,9 @@ static void dnc_fwd_lds(const DncDims& d, DncLds& L) {
     if (nslA * d.N > part) part = nslA * d.N;
     if (DW * d.R * 256 > part) part = DW * d.R * 256;                 // link pass: per-wave backward partials of one 256-column block
     const int RWd = d.R * d.W;
-    const int nslR = DT / RWd > 0 ? DT / RWd : 1;
-    if (nslR * RWd > part) part = nslR * RWd;
+    int nslR4 = DT / (RWd / 4) > 0 ? DT / (RWd / 4) : 1;              // reads: (head, float4 of the word) x row slices
+    if (nslR4 > d.N) nslR4 = d.N;
+    if (nslR4 * RWd > part) part = nslR4 * RWd;
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
     L.part = take(part);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
     const int nslG = max(1, DT / hid), kperG = (K + nslG - 1) / nslG;
     const int icg = IP >> 2, nslI = max(1, DT / icg), kperI = (hid + nslI - 1) / nslI;
     const int nslA = max(1, DT / N), mperA = (N + nslA - 1) / nslA;
-    const int nslR = max(1, DT / RWd), nperR = (N + nslR - 1) / nslR;
+    const int RW4 = RWd >> 2, nslR4 = min(max(1, DT / RW4), N), nperR4 = (N + nslR4 - 1) / nslR4;
 
     // ---- load state
     for (int i = tid0; i < N; i += DT) sU[i] = a.usage[(size_t)b * N + i];
@@ -157,10 +161,9 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
         if (tid < nslG * hid) {
             const int j = tid % hid, ks = tid / hid;
             const int k0 = ks * kperG, k1 = min(K, k0 + kperG);
+            // explicit two-batch stream: the rolled loop keeps ONE load in flight (common.h)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* wp = Wr4 + (size_t)k0 * hid + j;
-#pragma unroll 8
-            for (int k = k0; k < k1; ++k, wp += hid) acc += sZ[k] * (*wp);
+            if (k0 < k1) acc = ntk_stream_matvec<4>(Wr4 + j, hid, sZ, k0, k1, K);
             sPart4[ks * hid + j] = acc;
         }
         __syncthreads();
@@ -190,9 +193,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
             const int cg = tid % icg, ks = tid / icg;
             const int k0 = ks * kperI, k1 = min(hid, k0 + kperI);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* wp = Wi4 + (size_t)k0 * icg + cg;
-#pragma unroll 4
-            for (int k = k0; k < k1; ++k, wp += icg) acc += sZ[RWd + k] * (*wp);
+            if (k0 < k1) acc = ntk_stream_matvec<4>(Wi4 + cg, icg, sZ + RWd, k0, k1, hid);
             sPart4[ks * icg + cg] = acc;
         }
         __syncthreads();
@@ -230,22 +231,34 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
         {
             const int grp = tid / LPR, gl = tid % LPR, ngrp = DT / LPR;
             // key norms (tiny, recomputed by every group leader; keys are in LDS)
-            for (int n = grp; n < N; n += ngrp) {
-                f32x4 m = {0.f, 0.f, 0.f, 0.f};
-                if (gl < W4) m = reinterpret_cast<const f32x4*>(gM + (size_t)n * W)[gl];
-                float nsq = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3];
-                for (int o = LPR >> 1; o > 0; o >>= 1) nsq += __shfl_xor(nsq, o, 64);
-                for (int j = 0; j < Wn; ++j) {
-                    float dot = 0.f, ksq = 0.f;
-                    if (gl < W4) {
-                        const float* kp = sI + d.oKw + j * W + gl * 4;
-                        dot = kp[0] * m[0] + kp[1] * m[1] + kp[2] * m[2] + kp[3] * m[3];
-                        ksq = kp[0] * kp[0] + kp[1] * kp[1] + kp[2] * kp[2] + kp[3] * kp[3];
-                    }
-                    for (int o = LPR >> 1; o > 0; o >>= 1) { dot += __shfl_xor(dot, o, 64); ksq += __shfl_xor(ksq, o, 64); }
-                    if (gl == 0) {
-                        const float sim = dot / (sqrtf(ksq + EPS) * sqrtf(nsq + EPS) + EPS);
-                        sCW[j * N + n] = sim * sI[d.oBw + j];
+            // the rows of a group are requested DNC_PFM at a time (one L2 / Infinity-Cache round trip per batch, not per row)
+            for (int n0 = grp; n0 < N; n0 += ngrp * DNC_PFM) {
+                f32x4 mb[DNC_PFM];
+#pragma unroll
+                for (int u = 0; u < DNC_PFM; ++u) {
+                    const int n = n0 + u * ngrp;
+                    mb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (n < N && gl < W4) mb[u] = reinterpret_cast<const f32x4*>(gM + (size_t)n * W)[gl];
+                }
+#pragma unroll
+                for (int u = 0; u < DNC_PFM; ++u) {
+                    const int n = n0 + u * ngrp;
+                    if (n >= N) break;
+                    const f32x4 m = mb[u];
+                    float nsq = m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3];
+                    for (int o = LPR >> 1; o > 0; o >>= 1) nsq += __shfl_xor(nsq, o, 64);
+                    for (int j = 0; j < Wn; ++j) {
+                        float dot = 0.f, ksq = 0.f;
+                        if (gl < W4) {
+                            const float* kp = sI + d.oKw + j * W + gl * 4;
+                            dot = kp[0] * m[0] + kp[1] * m[1] + kp[2] * m[2] + kp[3] * m[3];
+                            ksq = kp[0] * kp[0] + kp[1] * kp[1] + kp[2] * kp[2] + kp[3] * kp[3];
+                        }
+                        for (int o = LPR >> 1; o > 0; o >>= 1) { dot += __shfl_xor(dot, o, 64); ksq += __shfl_xor(ksq, o, 64); }
+                        if (gl == 0) {
+                            const float sim = dot / (sqrtf(ksq + EPS) * sqrtf(nsq + EPS) + EPS);
+                            sCW[j * N + n] = sim * sI[d.oBw + j];
+                        }
                     }
                 }
             }
@@ -290,10 +303,20 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
         // ------------------------------------------------------------ P6: erase + write on M, read-key dots on M_t
         {
             const int grp = tid / LPR, gl = tid % LPR, ngrp = DT / LPR;
-            for (int n = grp; n < N; n += ngrp) {
-                f32x4 m = {0.f, 0.f, 0.f, 0.f};
+            for (int n0 = grp; n0 < N; n0 += ngrp * DNC_PFM) {
+              f32x4 mb[DNC_PFM];
+#pragma unroll
+              for (int u = 0; u < DNC_PFM; ++u) {
+                  const int n = n0 + u * ngrp;
+                  mb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                  if (n < N && gl < W4) mb[u] = reinterpret_cast<const f32x4*>(gM + (size_t)n * W)[gl];
+              }
+#pragma unroll
+              for (int u = 0; u < DNC_PFM; ++u) {
+                const int n = n0 + u * ngrp;
+                if (n >= N) break;
+                f32x4 m = mb[u];
                 if (gl < W4) {
-                    m = reinterpret_cast<const f32x4*>(gM + (size_t)n * W)[gl];
                     f32x4 E = {1.f, 1.f, 1.f, 1.f}, A = {0.f, 0.f, 0.f, 0.f};
                     for (int j = 0; j < Wn; ++j) {
                         const float wwn = sWW[j * N + n];
@@ -321,6 +344,7 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
                         sCR[i * N + n] = sim * sI[d.oBr + i];
                     }
                 }
+              }
             }
         }
         // ------------------------------------------------------------ P7: link pass (one read + one write of L)
@@ -342,11 +366,23 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) if (i < R) rwb[i] = *reinterpret_cast<const f32x4*>(sRW + i * N + b0);
                 }
-                for (int r = wave; r < N; r += DW) {
+                // a wave's rows in batches of DNC_PFL (1: at the 128 registers a 1024-thread workgroup leaves a thread, a batch of
+                // four rows spills 100+ registers -- measured; the rows are private to the wave)
+                for (int r0 = wave; r0 < N; r0 += DW * DNC_PFL) {
+                  f32x4 lcur[DNC_PFL];
+#pragma unroll
+                  for (int u = 0; u < DNC_PFL; ++u) {
+                      const int r = r0 + u * DW;
+                      lcur[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                      if (colok && r < N) lcur[u] = *reinterpret_cast<const f32x4*>(Lj + (size_t)r * N + b0);
+                  }
+#pragma unroll
+                  for (int u = 0; u < DNC_PFL; ++u) {
+                    const int r = r0 + u * DW;
+                    if (r < N) {                                 // wave-uniform
                     const float wwa = sWW[j * N + r];
-                    f32x4 l = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 l = lcur[u];
                     if (colok) {
-                        l = *reinterpret_cast<const f32x4*>(Lj + (size_t)r * N + b0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float v = (1.0f - wwa - wwb[e]) * l[e] + wwa * pb[e];
@@ -366,6 +402,9 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
                             accB[i] += sRW[i * N + r] * l;
                         }
                     }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // one row at a time: the scheduler otherwise hoists every row's LDS operands
+                  }
                 }
                 // fixed-order reduction of the per-wave backward partials of this column block
 #pragma unroll
@@ -418,19 +457,25 @@ __global__ __launch_bounds__(DT) void dnc_seq_fwd_kernel(DncFwdArgs a, DncLds L)
             }
         }
         __syncthreads();
-        if (tid < nslR * RWd) {                               // reads = rw x M_t
-            const int o = tid % RWd, sl = tid / RWd;
-            const int i = o / W, w = o - i * W;
-            const int n0 = sl * nperR, n1 = min(N, n0 + nperR);
-            float s = 0.f;
-#pragma unroll 8
-            for (int n = n0; n < n1; ++n) s += sRW[i * N + n] * gM[(size_t)n * W + w];
-            sPart[sl * RWd + o] = s;
+        if (tid < nslR4 * RW4) {                              // reads = rw x M_t: a thread = (head, float4 of the word) x row slice
+            const int o4 = tid % RW4, sl = tid / RW4;
+            const int i = o4 / W4, w4 = o4 - i * W4;
+            const int n0 = sl * nperR4, n1 = min(N, n0 + nperR4);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            const f32x4* mp = reinterpret_cast<const f32x4*>(gM) + w4;
+            for (int n = n0; n < n1; n += 4) {
+                f32x4 mv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mv[u] = mp[(size_t)min(n + u, N - 1) * W4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += ((n + u < n1) ? sRW[i * N + n + u] : 0.f) * mv[u];
+            }
+            reinterpret_cast<f32x4*>(sPart)[sl * RW4 + o4] = s;
         }
         __syncthreads();
         if (tid < RWd) {
             float s = 0.f;
-            for (int sl = 0; sl < nslR; ++sl) s += sPart[sl * RWd + tid];
+            for (int sl = 0; sl < nslR4; ++sl) s += sPart[sl * RWd + tid];
             sZ[tid] = s;
             if (rec) a.rec_yin[bt * d.ldy + hid + tid] = s;
         } else if (rec && tid >= RWd && tid < RWd + (d.ldy - d.Ky)) {
