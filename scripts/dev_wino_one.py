@@ -4,6 +4,8 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 from ntmtrack import vgg
 dev = torch.device("cuda")
 F, H, cin, cout = int(sys.argv[1]) if len(sys.argv) > 1 else 640, 56, 256, 256
+if len(sys.argv) > 3:                      # H,cin,cout of another layer shape
+    H, cin, cout = [int(v) for v in sys.argv[3].split(",")]
 algo = sys.argv[2] if len(sys.argv) > 2 else "wino"
 x = torch.randn((F, H, H, cin), device=dev)
 w = torch.randn((3, 3, cin, cout), device=dev) * 0.02
