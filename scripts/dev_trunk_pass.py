@@ -7,13 +7,13 @@ import torch
 from ntmtrack import vgg
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 640
-algo = sys.argv[2] if len(sys.argv) > 2 else "winograd"
+algo = sys.argv[2] if len(sys.argv) > 2 else "winograd"      # winograd | winograd2 | direct | bf16 (config 5's bf16 MFMA trunk)
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(42)
 ws = {}
 for name, cin, cout, _ in vgg.VGG_LAYERS:
     ws[name] = (torch.randn((3, 3, cin, cout), generator=g) * (2.0 / (9 * cin)) ** 0.5, torch.zeros(cout))
-net = vgg.VGG16Conv43(ws, device=dev, algo=algo)
+net = vgg.VGG16Conv43(ws, device=dev, dtype="bf16") if algo == "bf16" else vgg.VGG16Conv43(ws, device=dev, algo=algo)
 frames = (torch.rand((F, 224, 224, 3), generator=g) * 255 - 117.0).to(dev)
 out = torch.empty((F, 28, 28, 512), device=dev)
 for _ in range(3):
