@@ -26,11 +26,13 @@
 // Diagnostic build only (-DNTK_CL_PROF): see dnc_cluster_fwd.hip
 #ifdef NTK_CL_PROF
 __device__ unsigned long long g_clb_prof[32];
+// accumulators in global memory (no-return atomic adds by one thread): kept in registers (40 VGPRs) they made the record
+// prefetch of this 246-VGPR kernel spill, and the stamped build then measured its own spill traffic; LDS is full
 #define CLB_STAMP(i)                                                                  \
     do {                                                                              \
         if (blockIdx.x == 0 && tid == 0) {                                            \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
-            prof_acc[i] += now_ - prof_last;                                          \
+            __hip_atomic_fetch_add(&g_clb_prof[i], now_ - prof_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
             prof_last = now_;                                                         \
         }                                                                             \
     } while (0)
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         plain = __builtin_amdgcn_readfirstlane(same) != 0;
     }
 #ifdef NTK_CL_PROF
-    unsigned long long prof_acc[20] = {0}, prof_last = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && tid0 == 0) for (int i = 0; i < 20; ++i) g_clb_prof[i] = 0;
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
 #endif
     // the small per-step records are requested one step ahead (they stream from HBM: a step's own loads would sit on
     // its critical path): pf_* hold step t's values when step t starts
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         CLB_STAMP(17);
     }
 #ifdef NTK_CL_PROF
-    if (blockIdx.x == 0 && tid0 == 0) for (int i = 0; i < 20; ++i) g_clb_prof[i] = prof_acc[i];
+    (void)prof_last;
 #endif
 
     // ---- carried gradients out (segmented BPTT); d(memory) / d(link) scratch updated in place

@@ -42,6 +42,7 @@ if record:
           "reload M + B5ab link elementwise", "B5c MFMA + publish", "X0 wait", "X0 consume", "B6 precedence", "B7 write bwd pass", "B8/B9 alloc bwd",
           "B10b/B11/colsums/dxi", "B14/B15 dh + LSTM bwd", "B16 dz partial + publish", "X1 wait", "X1 consume"]
     totb = float(sum(bb))
-    print("cluster bwd: %.0f cycles/step (workgroup 0, stamped build)" % (totb / S))
+    print("cluster bwd: %.0f cycles/step (workgroup 0, stamped build; the stamps still cost ~30 spilled registers in this 246-VGPR kernel:"
+          " the product build is ~10 %% faster and the sections after a record prefetch read too high)" % (totb / S))
     for i, nm in enumerate(nb):
         print("  %-36s %8.0f cyc/step  %5.1f %%" % (nm, bb[i] / S, 100.0 * bb[i] / totb))
