@@ -17,6 +17,24 @@
 //   P8 erase/add write and read (reads see the pre-write memory unless write_first, Q6) (:202-215)
 #include "ntm_common.h"
 
+// Diagnostic build only (-DNTK_CL_PROF): s_memtime shares per phase, accumulated in LDS by thread 0 of workgroup 0
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_ntm_fwd_prof[16];
+#define NTM_STAMP(i)                                                        \
+    do {                                                                    \
+        if (blockIdx.x == 0 && tid == 0) {                                  \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+            s_prof[i] += now_ - s_prof[15];                                 \
+            s_prof[15] = now_;                                              \
+        }                                                                   \
+    } while (0)
+extern "C" int ntk_ntm_fwd_prof(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ntm_fwd_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#else
+#define NTM_STAMP(i) do { } while (0)
+#endif
+
 struct NtmFwdArgs {
     NtmDims d;
     // inputs
@@ -71,10 +89,20 @@ static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
 // FIX = true specialises every dimension to the reference defaults the benchmark configs run
 // (direct_offset_output.py:21-27: mem 128x20, hidden 200, 4 read + 1 write heads, shift_range 1,
 // output_dim 2, 640 threads): index arithmetic constant-folds and the small loops unroll.
-template <int MAXT, bool FIX>
+// FIXT = 512 with NTM_RES_REG / NTM_RES_LDS > 0 is the same specialisation with RESIDENT gate weights: 512 threads leave a
+// thread 256 registers, and 44 of the 140 rows of Wr a thread multiplies per step (one float4 gate column of its unit x half
+// of K) stay on the CU for the whole sequence -- 24 rows in registers, 20 in the 128 KB of LDS the state leaves free --
+// instead of streaming from L2 every step.  The stream of the remaining rows is requested first and lands while the
+// resident rows are multiplied; the products are summed in the same order as before.  Measured (scripts/dev_ntm_prof.py,
+// dev_ntm_timing.py): the gate stream is 51 % of a forward step and runs at the ~100 GB/s one CU draws from L2 however
+// deep the prefetch (16 or 24 rows per thread in flight: the same) and however lean the loop (a guard-free form with
+// scalar row bases: the same) -- only fewer bytes help: 912 -> 614 KB per step, forward 21.6 -> 20.3 ms at B32 x S1300.
+// LDS rows alone at 640 threads gave nothing (the other phases lose at 512 threads what 14 % fewer bytes win).
+template <int MAXT, int FIXT, int NTM_RES_REG = 0, int NTM_RES_LDS = 0>
 __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, T = FIX ? 640 : blockDim.x;
+    constexpr bool FIX = FIXT != 0, RES = NTM_RES_REG + NTM_RES_LDS > 0;
+    const int b = blockIdx.x, tid = threadIdx.x, T = FIX ? FIXT : blockDim.x;
     const int N = FIX ? 128 : a.d.N, Md = FIX ? 20 : a.d.Md, MP = Md | 1, R = FIX ? 4 : a.d.R, Wh = FIX ? 1 : a.d.Wh;
     const int H = R + Wh, hid = FIX ? 200 : a.d.hid, SS = FIX ? 3 : a.d.SS;
     const int S = a.d.S, RM = R * Md, K = RM + hid;
@@ -123,6 +151,22 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
     f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
 
     const int tid0 = tid;
+    f32x4 wres[NTM_RES_REG > 0 ? NTM_RES_REG : 1];
+    const f32x4* sWres4 = reinterpret_cast<const f32x4*>(smem + L.total + 32);     // [NTM_RES_LDS][nsl * hid] behind the state (+ the diagnostic words)
+    if constexpr (RES) {
+        if (tid < nsl * hid) {
+            const int j = tid % hid, ks = tid / hid, k0 = ks * kper;
+#pragma unroll
+            for (int q = 0; q < NTM_RES_REG; ++q) wres[q] = Wr4[(size_t)min(k0 + q, a.d.ldz - 1) * hid + j];
+            f32x4* wl = reinterpret_cast<f32x4*>(smem + L.total + 32);
+            for (int q = 0; q < NTM_RES_LDS; ++q) wl[q * (nsl * hid) + tid] = Wr4[(size_t)min(k0 + NTM_RES_REG + q, a.d.ldz - 1) * hid + j];
+        }
+        __syncthreads();
+    }
+#ifdef NTK_CL_PROF
+    unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + L.total);      // 128 B behind the state (the launch adds them)
+    if (tid == 0) { for (int i = 0; i < 15; ++i) s_prof[i] = 0; s_prof[15] = __builtin_amdgcn_s_memtime(); }
+#endif
     for (int t = 0; t < S; ++t) {
         // re-derive every thread-index expression inside the step: an opaque copy of the thread id keeps
         // the compiler from hoisting dozens of loop-invariant addresses out of the t-loop and spilling them
@@ -151,11 +195,20 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             constexpr int PF = 8;
             f32x4 wa[PF], wb[PF];
             const int klast = a.d.ldz - 1;          // last row of the Wr allocation (a zero pad row)
+            const int ks0 = RES ? min(k1, k0 + NTM_RES_REG + NTM_RES_LDS) : k0;      // first streamed row
 #pragma unroll
-            for (int q = 0; q < PF; ++q) wa[q] = wp[(size_t)min(k0 + q, klast) * hid];
+            for (int q = 0; q < PF; ++q) wa[q] = wp[(size_t)min(ks0 + q, klast) * hid];
 #pragma unroll
-            for (int q = 0; q < PF; ++q) wb[q] = wp[(size_t)min(k0 + PF + q, klast) * hid];
-            for (int k = k0; k < k1; k += 2 * PF) {
+            for (int q = 0; q < PF; ++q) wb[q] = wp[(size_t)min(ks0 + PF + q, klast) * hid];
+            if constexpr (RES) {                    // the resident rows, while the first streamed batches are in flight
+#pragma unroll
+                for (int q = 0; q < NTM_RES_REG; ++q) acc += ((k0 + q < k1) ? sZ[k0 + q] : 0.f) * wres[q];
+#pragma unroll 4
+                for (int q = 0; q < NTM_RES_LDS; ++q)
+                    acc += ((k0 + NTM_RES_REG + q < k1) ? sZ[k0 + NTM_RES_REG + q] : 0.f) * sWres4[q * (nsl * hid) + tid];
+            }
+#pragma nounroll
+            for (int k = ks0; k < k1; k += 2 * PF) {
 #pragma unroll
                 for (int q = 0; q < PF; ++q) {
                     const float zk = (k + q < k1) ? sZ[k + q] : 0.f;
@@ -174,6 +227,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             sPart4[ks * hid + j] = acc;
         }
         __syncthreads();
+        NTM_STAMP(0);
         // ------------------------------------------------------------ P2: LSTM cell  ||  column norms of M (Q1)
         const int wave = tid >> 6, nwaves = T >> 6;
         if (tid < hid) {
@@ -208,6 +262,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             }
         }
         __syncthreads();
+        NTM_STAMP(1);
         // ------------------------------------------------------------ P3: unpack / output partials
         if (tid < nslB * ncg) {
             const int cg = tid % ncg, ks = tid / ncg;
@@ -216,6 +271,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             sPart4[ks * ncg + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 4)>(Wa4 + cg, ncg, sZ + RM, k0, k1, hid);
         }
         __syncthreads();
+        NTM_STAMP(2);
         // ------------------------------------------------------------ P4: control activations
         if (tid < PP) {
             float v = a.Wa[(size_t)hid * PP + tid];
@@ -233,6 +289,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             if (tid >= d.P && tid < d.P + d.O) a.logits[bt * d.O + (tid - d.P)] = v;
         }
         __syncthreads();
+        NTM_STAMP(3);
         // ------------------------------------------------------------ P5-P7: one WAVE per head, no workgroup barrier inside:
         // key scaling, similarity (Q1), beta, softmax over N, gate, circular shift (Q2), sharpen (Q4)
         if (wave < H) {
@@ -306,6 +363,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             for (int j = 0; j < d.O; ++j) a.outputs[bt * d.O + j] = expf(sU[d.P + j] - mx) / sum;
         }
         __syncthreads();
+        NTM_STAMP(4);
         // ------------------------------------------------------------ P8: write + read
         auto update_M = [&]() {
             for (int idx = tid; idx < N * Md; idx += T) {
@@ -326,11 +384,17 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             const int o = tid % RM, sl = tid / RM;
             const int i = o / Md, m = o - i * Md;
             const int n0 = sl * nperR, n1 = min(N, n0 + nperR);
-            float s = 0.f;
-            for (int n = n0; n < n1; ++n) s += sW[i * N + n] * sM[n * MP + m];
-            sPart[sl * RM + o] = s;
+            float s0 = 0.f, s1 = 0.f;                 // two chains: the loop is bound by the add latency, not by LDS
+            int n = n0;
+            for (; n + 1 < n1; n += 2) {
+                s0 += sW[i * N + n] * sM[n * MP + m];
+                s1 += sW[i * N + n + 1] * sM[(n + 1) * MP + m];
+            }
+            if (n < n1) s0 += sW[i * N + n] * sM[n * MP + m];
+            sPart[sl * RM + o] = s0 + s1;
         }
         __syncthreads();
+        NTM_STAMP(5);
         if (!d.write_first) update_M();
         if (tid < RM) {
             float s = 0.f;
@@ -339,7 +403,11 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             if (a.st_read) a.st_read[bt * RM + tid] = s;
         }
         __syncthreads();
+        NTM_STAMP(6);
     }
+#ifdef NTK_CL_PROF
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 16; ++i) g_ntm_fwd_prof[i] = s_prof[i];
+#endif
 
     // ---- final state
     for (int i = tid; i < N * Md; i += T) a.M_out[(size_t)b * N * Md + i] = sM[(i / Md) * MP + (i % Md)];
@@ -419,23 +487,29 @@ extern "C" int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int h
     a.logits = logits; a.outputs = outputs; a.M_out = M_out; a.w_out = w_out; a.read_out = read_out; a.cs_out = cs_out;
     a.st_z = st_z; a.st_gates = st_gates; a.st_c = st_c; a.st_h = st_h; a.st_u = st_u;
     a.st_wc = st_wc; a.st_wv = st_wv; a.st_w = st_w; a.st_M = st_M; a.st_read = st_read;
-    const int T = ntm_pick_threads(a.d);
+    int T = ntm_pick_threads(a.d);
     NTK_REQUIRE(T >= a.d.N, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_fwd: mem_size %d exceeds the workgroup", a.d.N);
     NtmLds L;
     ntm_fwd_lds(a.d, T, L);
-    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    const bool fixdims = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2);
+    const char* ev = getenv("NTK_NTM_FWD_VARIANT");                      // dev switch: 0 = the all-streaming 640-thread specialisation
+    const int variant = fixdims ? (ev ? atoi(ev) : 1) : 0;
+    if (variant == 1) { T = 512; ntm_fwd_lds(a.d, T, L); }
+    size_t lds_bytes = (size_t)L.total * sizeof(float) + 128;                    // + the diagnostic build's stamp words
+    if (variant == 1) lds_bytes += (size_t)20 * 2 * hid * sizeof(f32x4);
     NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED,
                 "ntk_ntm_seq_fwd: state needs %zu B of LDS (> 160 KiB)", lds_bytes);
     {
         static NtkLdsAttrCache lds_cache;
-        const void* const ks[] = {(const void*)ntm_seq_fwd_kernel<768, false>, (const void*)ntm_seq_fwd_kernel<1024, false>, (const void*)ntm_seq_fwd_kernel<768, true>};
-        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 3, "ntk_ntm_seq_fwd");
+        const void* const ks[] = {(const void*)ntm_seq_fwd_kernel<768, 0>, (const void*)ntm_seq_fwd_kernel<1024, 0>, (const void*)ntm_seq_fwd_kernel<768, 640>,
+                                  (const void*)ntm_seq_fwd_kernel<512, 512, 24, 20>};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 4, "ntk_ntm_seq_fwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
-    const bool fix = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2 && T == 640);
-    if (fix) ntm_seq_fwd_kernel<768, true><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
-    else if (T <= 768) ntm_seq_fwd_kernel<768, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
-    else ntm_seq_fwd_kernel<1024, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    if (variant == 1) ntm_seq_fwd_kernel<512, 512, 24, 20><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else if (fixdims && T == 640) ntm_seq_fwd_kernel<768, 640><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else if (T <= 768) ntm_seq_fwd_kernel<768, 0><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else ntm_seq_fwd_kernel<1024, 0><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     NTK_CHECK_LAUNCH("ntk_ntm_seq_fwd");
     return NTK_OK;
 }
