@@ -15,6 +15,24 @@
 // rsqrt(max(sum x^2, 1e-12)) (zero through the norm when clamped).
 #include "ntm_common.h"
 
+// Diagnostic build only (-DNTK_CL_PROF): s_memtime shares between consecutive workgroup barriers of a step (LDS accumulators)
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_ntm_bwd_prof[16];
+#define NTMB_STAMP(i)                                                       \
+    do {                                                                    \
+        if (blockIdx.x == 0 && tid == 0) {                                  \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+            s_prof[i] += now_ - s_prof[15];                                 \
+            s_prof[15] = now_;                                              \
+        }                                                                   \
+    } while (0)
+extern "C" int ntk_ntm_bwd_prof(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ntm_bwd_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#else
+#define NTMB_STAMP(i) do { } while (0)
+#endif
+
 struct NtmBwdArgs {
     NtmDims d;
     const float* WrT;      // [4*hid][ldkT]  transposed recurrent weights (rows n' = unit*4+gate)
@@ -39,6 +57,7 @@ constexpr int NQ = 6;        // max simultaneous per-head reductions in one stag
 constexpr int NQT = 11;      // reduction slots per head; every stage owns its own slots (no read/write reuse inside a step)
 constexpr int QR1 = 0, QR2 = 2, QR3 = 8, QR4 = 10;
 constexpr int MAXM = 8;      // max memory elements prefetched per thread
+constexpr int NTMB_RES_WA = 7;   // benchmark shape: rows of Wa^T per thread (of its 15) kept in the LDS the state leaves free
 
 static void ntm_bwd_lds(const NtmDims& d, int T, int ldkT, int ldhT, NtmBwdLds& L) {
     const int MP = d.Md | 1, NM = d.N * MP, HN = d.H * d.N;
@@ -182,6 +201,23 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         return s;
     };
 
+    // benchmark shape: 7 of the 15 rows of Wa^T a thread multiplies in B9 stay in LDS for the whole sequence (67 KB of the 74 KB
+    // the state leaves free); B9's stream runs at ~67 GB/s, the worst of the kernel's three weight streams
+    const f32x4* sWaRes4 = reinterpret_cast<const f32x4*>(smem + L.total + 32);
+    if constexpr (FIX) {
+        if (tid0 < nslH * hg4) {
+            const int cg = tid0 % hg4, sl = tid0 / hg4;
+            const int c0 = sl * nperH, c1 = min(PP, c0 + nperH);
+            f32x4* wl = reinterpret_cast<f32x4*>(smem + L.total + 32);
+            for (int q = 0; q < NTMB_RES_WA; ++q)
+                wl[q * (nslH * hg4) + tid0] = (c0 + q < c1) ? reinterpret_cast<const f32x4*>(a.WaT)[(size_t)(c0 + q) * hg4 + cg] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+    }
+#ifdef NTK_CL_PROF
+    unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + L.total);      // 128 B behind the state (the launch adds them)
+    if (threadIdx.x == 0) { for (int i = 0; i < 15; ++i) s_prof[i] = 0; s_prof[15] = __builtin_amdgcn_s_memtime(); }
+#endif
     for (int t = S - 1; t >= 0; --t) {
         // opaque thread id: keeps loop-invariant index/address expressions from being hoisted out of the
         // t-loop (they would be spilled to scratch and reloaded every step)
@@ -195,6 +231,25 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         if (t > 0) prefetch(t - 1);
 
         // ------------------------------------------------ X1: memory-shaped elementwise + column norms + small vectors
+        if constexpr (FIX) {
+            // benchmark shape (write_first off): a thread = (slot n, four adjacent columns): the five head weights of the slot
+            // are read once for four elements and d(read) comes in 16-byte reads: 29 LDS operations per thread instead of 52
+            const int n = tid / 5, m0 = (tid - n * 5) * 4;
+            float wt[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) wt[i] = sWt[i * N + n];
+            f32x4 dmr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dmr += wt[i] * *reinterpret_cast<const f32x4*>(sdZ + i * Md + m0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ai = n * MP + m0 + e;
+                const float dMt = sdM[ai];
+                const float E = 1.0f - wt[4] * sU[d.oE + m0 + e];
+                sG[ai] = dMt;
+                sdM[ai] = dMt * E + dmr[e];
+            }
+        } else
         for (int idx = tid; idx < NMd; idx += T) {
             const int n = idx / Md, m = idx - n * Md, ai = n * MP + m;
             float dMt = sdM[ai];
@@ -226,6 +281,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             for (int j = 0; j < SS; ++j) sSw[h * SS + j] = expf(sU[d.oS + h * SS + j] - mx) / sum;
         }
         __syncthreads();
+        NTMB_STAMP(0);
 
         // ------------------------------------------------ X2: d(w_t) for every head; R1 sums
         float dwt = 0.f, pw = 0.f, wv = 0.f, wt = 0.f, wc = 0.f, wp = 0.f, gam = 1.f, gate = 0.f;
@@ -262,6 +318,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         red_write(rv, 2, QR1);
         __syncthreads();
+        NTMB_STAMP(1);
 
         // ------------------------------------------------ R2: sharpen backward, shift-weight sums
         float dpw = 0.f, dwv = 0.f;
@@ -289,6 +346,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         red_write(rv, 1 + SS, QR2);
         __syncthreads();
+        NTMB_STAMP(2);
 
         // ------------------------------------------------ R3: shift + gate backward
         float dwg = 0.f, dwc = 0.f;
@@ -309,6 +367,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         red_write(rv, 2, QR3);
         __syncthreads();
+        NTMB_STAMP(3);
 
         // ------------------------------------------------ R4: content softmax backward
         float Sg = 0.f, dv = 0.f;
@@ -323,6 +382,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         red_write(rv, 1, QR4);
         __syncthreads();
+        NTMB_STAMP(4);
         if (hn && nn == 0) {       // per-head scalar controls -> raw gradients
             const int h = hh;
             const float beta = sU[d.oB + h];
@@ -336,6 +396,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             for (int j = 0; j < NQ - 1; ++j) if (j < SS) sDU[d.oS + h * SS + j] = sSw[h * SS + j] * (Ssw[j] - dot);
         }
 
+        NTMB_STAMP(12);
         // ------------------------------------------------ B7: dMhat[n][m] = sum_h dsim[h][n] khat[h][m], computed ONCE
         //                                                  (the column-norm sum and the d(M_prev) update both use it);
         //                                                  reductions over slots (keys, erase, add)
@@ -345,34 +406,75 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             for (int h = 0; h < H; ++h) dmh += sDsim[h * N + n] * sKhat[h * Md + m];
             sDmh[n * MP + m] = dmh;
         }
-        if (tid < nslP * nout) {
+        NTMB_STAMP(13);
+        if constexpr (FIX) {
+            // benchmark shape (5 heads, 1 write head): a thread = (memory column m = tid >> 4, row class sl = tid & 15) reads
+            // M_prev[n][m], G[n][m], ww[n] and dsim[0..4][n] ONCE per row n = sl, sl + 16, ... and feeds seven sums; the sixteen
+            // row classes of a column are sixteen adjacent lanes, reduced on the DPP path: 20 K LDS reads per step instead of 41 K,
+            // no slot partials (the one-output-per-thread form below was 14 % of a BPTT step)
+            if (tid < 16 * Md) {
+                const int m = tid >> 4, sl = tid & 15;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, ae = 0.f, aa = 0.f;
+#pragma unroll 4
+                for (int n = sl; n < N; n += 16) {
+                    const float mp = sMp[n * MP + m], g = sG[n * MP + m], ww = sWt[R * N + n];
+                    a0 += sDsim[0 * N + n] * mp; a1 += sDsim[1 * N + n] * mp; a2 += sDsim[2 * N + n] * mp;
+                    a3 += sDsim[3 * N + n] * mp; a4 += sDsim[4 * N + n] * mp;
+                    const float wg = ww * g;
+                    ae -= wg * mp;
+                    aa += wg;
+                }
+                auto r16 = [](float v) { v += ntk_dpp<0xB1>(v); v += ntk_dpp<0x4E>(v); v += ntk_dpp<0x141>(v); v += ntk_dpp<0x140>(v); return v; };
+                a0 = r16(a0); a1 = r16(a1); a2 = r16(a2); a3 = r16(a3); a4 = r16(a4); ae = r16(ae); aa = r16(aa);
+                if (sl == 0) {
+                    sPart[0 * Md + m] = a0; sPart[1 * Md + m] = a1; sPart[2 * Md + m] = a2; sPart[3 * Md + m] = a3; sPart[4 * Md + m] = a4;
+                    sPart[H * Md + m] = ae; sPart[H * Md + Wh * Md + m] = aa;
+                }
+            }
+        } else if (tid < nslP * nout) {
             const int o = tid % nout, sl = tid / nout;
             const int n0 = sl * nperP, n1 = min(N, n0 + nperP);
             float s = 0.f;
             if (o < H * Md) {                                  // sum_n dsim[h][n] * M_prev[n][m]
                 const int h = o / Md, m = o - h * Md;
-                for (int n = n0; n < n1; ++n) s += sDsim[h * N + n] * sMp[n * MP + m];
+                // four independent chains, four rows per trip: the rolled single-chain loop paid an LDS round trip + the add
+                // latency per row (this phase was 18 % of a BPTT step)
+                float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int n = n0;
+                for (; n + 3 < n1; n += 4) {
+                    s += sDsim[h * N + n] * sMp[n * MP + m];
+                    s1 += sDsim[h * N + n + 1] * sMp[(n + 1) * MP + m];
+                    s2 += sDsim[h * N + n + 2] * sMp[(n + 2) * MP + m];
+                    s3 += sDsim[h * N + n + 3] * sMp[(n + 3) * MP + m];
+                }
+                for (; n < n1; ++n) s += sDsim[h * N + n] * sMp[n * MP + m];
+                s = (s + s1) + (s2 + s3);
             } else {
                 const int o2 = o - H * Md;
                 const int which = o2 / (Wh * Md);              // 0: erase, 1: add
                 const int jm = o2 - which * Wh * Md;
                 const int j = jm / Md, m = jm - j * Md;
+                float sa = 0.f, sb = 0.f;                       // two chains (even / odd rows)
                 for (int n = n0; n < n1; ++n) {
                     const float ww = sWt[(R + j) * N + n];
                     const float g = sG[n * MP + m];
+                    float term;
                     if (which == 0) {
                         float oth = 1.f;
                         for (int j2 = 0; j2 < Wh; ++j2)
                             if (j2 != j) oth *= (1.0f - sWt[(R + j2) * N + n] * sU[d.oE + j2 * Md + m]);
-                        s += -ww * g * sMp[n * MP + m] * oth;
+                        term = -ww * g * sMp[n * MP + m] * oth;
                     } else {
-                        s += ww * g;
+                        term = ww * g;
                     }
+                    if ((n - n0) & 1) sb += term; else sa += term;
                 }
+                s = sa + sb;
             }
             sPart[sl * nout + o] = s;
         }
         __syncthreads();
+        NTMB_STAMP(5);
         // column-norm term: s_m = sum_n dMhat[n][m] * M_prev[n][m], one wave_sum per column (waves stride over m)
         for (int m = (tid >> 6); m < Md; m += (T >> 6)) {
             float s = 0.f;
@@ -385,7 +487,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         if (tid < nout) {
             float s = 0.f;
-            for (int sl = 0; sl < nslP; ++sl) s += sPart[sl * nout + tid];
+            for (int sl = 0; sl < (FIX ? 1 : nslP); ++sl) s += sPart[sl * nout + tid];
             if (tid < H * Md) {
                 sDkhat[tid] = s * sCinv[tid % Md];
             } else {
@@ -397,6 +499,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             }
         }
         __syncthreads();
+        NTMB_STAMP(6);
         if (tid < H * Md) {
             const int h = tid / Md;
             float dot = 0.f;
@@ -412,15 +515,26 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             sdM[ai] += sCinv[m] * sDmh[ai] + sMp[ai] * sC2[m];
         }
         __syncthreads();
+        NTMB_STAMP(7);
         if (tid < PP) a.du[bt * PP + tid] = sDU[tid];
 
         // ------------------------------------------------ B9: dh' = carried dh + dU . Wa^T
         if (tid < nslH * hg4) {
             const int cg = tid % hg4, sl = tid / hg4;
             const int c0 = sl * nperH, c1 = min(PP, c0 + nperH);
-            sPart4[sl * hg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 4)>(reinterpret_cast<const f32x4*>(a.WaT) + cg, hg4, sDU, c0, c1, PP - 1);
+            if constexpr (FIX) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int cs = min(c1, c0 + NTMB_RES_WA);
+                const f32x4 str = ntk_stream_matvec<4>(reinterpret_cast<const f32x4*>(a.WaT) + cg, hg4, sDU, cs, c1, PP - 1);
+#pragma unroll
+                for (int q = 0; q < NTMB_RES_WA; ++q) acc += ((c0 + q < c1) ? sDU[c0 + q] : 0.f) * sWaRes4[q * (nslH * hg4) + tid];
+                sPart4[sl * hg4 + cg] = acc + str;
+            } else {
+                sPart4[sl * hg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 4)>(reinterpret_cast<const f32x4*>(a.WaT) + cg, hg4, sDU, c0, c1, PP - 1);
+            }
         }
         __syncthreads();
+        NTMB_STAMP(8);
         // ------------------------------------------------ B10: LSTM cell backward
         if (tid < hid) {
             float dh = sdZ[RM + tid];
@@ -439,6 +553,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             reinterpret_cast<f32x4*>(a.dgates)[bt * hid + tid] = dg;
         }
         __syncthreads();
+        NTMB_STAMP(9);
         // ------------------------------------------------ B11: d[read_prev; h_prev] = dgates . Wr^T
         if (tid < nslZ * kg4) {
             const int cg = tid % kg4, sl = tid / kg4;
@@ -446,6 +561,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             sPart4[sl * kg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 8)>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, r0, r1, 4 * hid - 1);
         }
         __syncthreads();
+        NTMB_STAMP(10);
         if (tid < K) {
             float s = 0.f;
             for (int sl = 0; sl < nslZ; ++sl) s += sPart[sl * ldkT + tid];
@@ -453,8 +569,12 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         if (t > 0) commit();       // next (earlier) step's records: every reader of the old ones has passed a barrier
         __syncthreads();
+        NTMB_STAMP(11);
     }
 
+#ifdef NTK_CL_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 16; ++i) g_ntm_bwd_prof[i] = s_prof[i];
+#endif
     // ---- gradient of the initial state
     for (int i = tid; i < NMd; i += T) a.dM0[(size_t)b * NMd + i] = sdM[(i / Md) * MP + (i % Md)];
     for (int i = tid; i < HN; i += T) a.dw0[(size_t)b * HN + i] = sdW[i];
@@ -532,7 +652,10 @@ extern "C" int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int h
     a.dgates = dgates; a.du = du; a.dM0 = dM0; a.dw0 = dw0; a.dread0 = dread0; a.dcs0 = dcs0;
     NtmBwdLds L;
     ntm_bwd_lds(a.d, T, ldkT, ldhT, L);
-    const size_t lds_bytes = (size_t)L.total * sizeof(float);
+    const bool fix = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2 &&
+                      T == 640 && !write_first && ldkT == 280 && ldhT == 200);
+    size_t lds_bytes = (size_t)L.total * sizeof(float) + 128;                // + the diagnostic build's stamp words
+    if (fix) lds_bytes += (size_t)NTMB_RES_WA * (T / (ldhT / 4)) * (ldhT / 4) * sizeof(f32x4);     // resident rows of Wa^T
     NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_bwd: needs %zu B of LDS (> 160 KiB)", lds_bytes);
     {
         static NtkLdsAttrCache lds_cache;
@@ -540,8 +663,6 @@ extern "C" int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int h
         const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 3, "ntk_ntm_seq_bwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
-    const bool fix = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2 &&
-                      T == 640 && !write_first && ldkT == 280 && ldhT == 200);
     if (fix) ntm_seq_bwd_kernel<768, true><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     else if (T <= 768) ntm_seq_bwd_kernel<768, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     else ntm_seq_bwd_kernel<1024, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);

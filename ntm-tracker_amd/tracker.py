@@ -8,6 +8,7 @@ the clip, so every rank applies the identical update -- the same result as a
 single process running the global batch, because the loss is an un-normalised
 sum (direct_offset_output.py:606).
 """
+import os
 import torch
 
 from . import _lib
@@ -128,11 +129,15 @@ class _TwoStreamPipeline(object):
         self._pending = []
         self._next_slot = 0
         self._proj_done = None      # event: input projection of the batch being trained is enqueued/done
+        self.trunk_waits_for_projection = os.environ.get("NTK_TRUNK_WAITS_FOR_PROJECTION", "0") != "0"
 
     def _mark_projection(self):
-        """Called by the core's forward pass right after the input-projection GEMM: the next trunk pass waits for
-        this point, so the (tiny, parameter-dependent) projection at the head of the strictly serial recurrent
-        chain runs on an idle chip instead of queueing behind the HBM-bound conv1_1 of the next batch."""
+        """Called by the core's forward pass right after the input-projection GEMM.  With
+        `trunk_waits_for_projection` (NTK_TRUNK_WAITS_FOR_PROJECTION=1; round 1's default) the next trunk pass waits
+        for this point, so the projection at the head of the serial recurrent chain runs on an idle chip instead of
+        queueing behind conv1_1 of the next batch.  Since round 2 the chain has slack against the trunk (it is the
+        trunk stream that bounds a step) and the 0.5 ms the trunk stream idled there cost more than the projection
+        gains: measured 64.62 -> 64.51 ms per step (configs[1]), 125.7 -> 124.2 ms (configs[2]); default off."""
         if self._s_ntm is not None:
             self._proj_done = torch.cuda.Event()
             self._proj_done.record(torch.cuda.current_stream(self.device))
@@ -157,7 +162,8 @@ class _TwoStreamPipeline(object):
         self._next_slot ^= 1
         s_vgg.wait_stream(torch.cuda.current_stream(self.device))       # frames were produced on the caller's stream
         if self._proj_done is not None:
-            s_vgg.wait_event(self._proj_done)                            # see _mark_projection (no-op if already passed)
+            if self.trunk_waits_for_projection:
+                s_vgg.wait_event(self._proj_done)                        # see _mark_projection (no-op if already passed)
             self._proj_done = None
         if slot["free"] is not None:
             s_vgg.wait_event(slot["free"])                               # core pass that last read this buffer is done

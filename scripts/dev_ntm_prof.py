@@ -26,3 +26,22 @@ tot = float(sum(buf[:7]))
 print("ntm fwd B=%d S=%d record=%s: %.0f cycles/step (workgroup 0, stamped build)" % (B, S, record, tot / S))
 for i, nm in enumerate(names):
     print("  %-36s %8.0f cyc/step  %5.1f %%" % (nm, buf[i] / S, 100.0 * buf[i] / tot))
+
+# ---- BPTT kernel: shares between consecutive workgroup barriers of a step
+_loss_offs = (torch.rand((B, T, 2), generator=g) - 0.5).to(dev)
+logits, _o, new, rec = trk.cell.run_sequence(X, st0, record=True, want_outputs=False)
+loss, pred, dlog = tracker.offset_loss(logits, _loss_offs, T)
+for _ in range(2):
+    trk.cell.backward_sequence(X, st0, rec, dlog)
+torch.cuda.synchronize()
+fnb = _lib.lib().ntk_ntm_bwd_prof
+fnb.restype = ctypes.c_int
+bb = (ctypes.c_ulonglong * 16)()
+assert fnb(bb) == 0
+nb = ["X1 memory-shaped elementwise, column norms", "X2 d(w_t) per head, R1 sums", "R2 sharpen bwd", "R3 shift + gate bwd", "R4 content softmax bwd",
+      "B7 dMhat (to its first barrier)", "B7/B8 second part", "B8 third part", "B9 dh = dU . Wa^T (Wa^T stream)", "B10 LSTM cell bwd",
+      "B11 d[read;h] = dgates . Wr^T (Wr^T stream)", "B11 reduce + carry", "(B7a) per-head scalar controls", "(B7b) dMhat loop"]
+totb = float(sum(bb[:14]))
+print("ntm bwd: %.0f cycles/step (workgroup 0, stamped build)" % (totb / S))
+for i, nm in enumerate(nb):
+    print("  %-48s %8.0f cyc/step  %5.1f %%" % (nm, bb[i] / S, 100.0 * bb[i] / totb))
