@@ -12,6 +12,10 @@ echo "c2 profile done"
 timeout -k 10 400 python3 bench.py --model dnc > $OUT/bench_dnc_c3.json 2> $OUT/bench_dnc_c3.err
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_dnc -- python3 bench.py --model dnc --no-cpu-baseline > $OUT/bench_dnc_c3_under_rocprof.json 2> $OUT/prof_dnc.err
 echo "dnc profile done"
+python3 scripts/trace_union.py $(ls -t $OUT/prof_c2/*/*_kernel_trace.csv | head -1) > $OUT/bench_c2_trunk_intervals.txt
+cat $OUT/bench_c2_trunk_intervals.txt
+# per-layer counters: one launch per layer and pass (the product splits a pass over two streams: two launches per layer)
+export NTK_TRUNK_SPLIT=1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
