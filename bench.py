@@ -398,8 +398,10 @@ def main():
                          "algorithmic_tflops": round(algorithmic, 2),
                          "note": ("achieved / frac = EXECUTED MFMA flops (conv1_1 direct + %.4f of the direct-convolution count for the "
                                   "nine Winograd layers) / trunk time measured with HIP events on the trunk's stream inside the timed "
-                                  "region; algorithmic_tflops = the direct-convolution count (SURVEY 8d: 27.92 GFLOP/frame) / the same time")
-                                 % WINO_EXECUTED_FRACTION[args.conv_algo]
+                                  "region; algorithmic_tflops = the direct-convolution count (SURVEY 8d: 27.92 GFLOP/frame) / the same time"
+                                  "; the trunk pass runs as %d stream part(s): with 2, kernel durations in a rocprof --stats summary overlap "
+                                  "pairwise (scripts/trace_union.py gives the union of their intervals per pass)")
+                                 % (WINO_EXECUTED_FRACTION[args.conv_algo], getattr(trk.vgg, "split_streams", 1))
                                  if wino else "direct convolution: executed = algorithmic flops"},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},

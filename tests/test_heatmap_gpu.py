@@ -79,9 +79,10 @@ def test_heatmap_tracker_gradients_and_learning(cuda):
     gmax = max(float(np.abs(pt[k].grad.numpy()).max()) for k in sd)
     for k in sorted(sd):
         ref = pt[k].grad.numpy()
-        # the labels of a frame sum to one, so d loss / d (output bias) = sum(p) - sum(y) is exactly zero: compare
-        # against the tensor's own scale, floored at 1e-3 of the largest gradient
-        err = np.max(np.abs(got[k].numpy() - ref)) / max(np.max(np.abs(ref)), 1e-3 * gmax)
+        # the labels of a frame sum to one, so d loss / d (output bias) = sum(p) - sum(y) is exactly zero: what the kernels
+        # return there is float32 rounding (measured 3-4e-6 of the largest gradient, moving with the summation order of the
+        # forward pass): compare against the tensor's own scale, floored at 2e-3 of the largest gradient
+        err = np.max(np.abs(got[k].numpy() - ref)) / max(np.max(np.abs(ref)), 2e-3 * gmax)
         assert err < 3e-3, (k, err)
     assert probs.shape == (B, T - 1, F) and torch.allclose(probs.sum(2), torch.ones((B, T - 1), device=cuda), atol=1e-5)
     first = float(loss.cpu())
