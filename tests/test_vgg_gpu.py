@@ -243,6 +243,33 @@ def test_vgg_trunk_winograd_equals_direct_fullsize(cuda):
     assert _rel(y4, yd) < 2e-5
 
 
+def test_vgg_trunk_stream_parts_do_not_change_the_result(cuda):
+    """The default trunk runs a pass as two half batches on two streams (they fill each other's launch tails): the
+    features are bit-identical to a one-stream pass and to a three-part pass, on the caller's current stream and on a side
+    stream, and a consumer that only orders itself after the caller's stream sees the finished buffer."""
+    from ntmtrack import vgg
+    rng = np.random.default_rng(11)
+    ws = O.init_vgg_weights(rng)
+    frames = torch.from_numpy((rng.uniform(0, 255, size=(96, 64, 64, 3)).astype(np.float32) - O.VGG_MEAN)).to(cuda)
+    net = vgg.VGG16Conv43(ws, device=cuda, algo="winograd")
+    assert net.split_streams == 2
+    y2 = net(frames).clone()
+    net.split_streams = 1
+    y1 = net(frames).clone()
+    net.split_streams = 3
+    y3 = net(frames).clone()
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
+    net.split_streams = 2
+    side = torch.cuda.Stream(device=cuda)
+    out = torch.zeros_like(y1)
+    side.wait_stream(torch.cuda.current_stream(cuda))
+    with torch.cuda.stream(side):
+        net(frames, out=out)
+        total = out.sum()                     # ordered after the pass on the caller's (side) stream only
+    torch.cuda.current_stream(cuda).wait_stream(side)
+    assert torch.equal(out, y1) and float(total) == float(y1.sum())
+
+
 def test_vgg_trunk_fullsize_matches_float64_oracle(cuda):
     """One 224x224 frame (plus a second, so frame strides are exercised) through the DEFAULT trunk (conv1_1 direct +
     nine fused Winograd F(4x4,3x3) layers: the 8x4x1 tile path at W = 224, 4x4x2 at 112, 2x2x8 at 56, 1x1x32 at 28),
