@@ -1148,7 +1148,12 @@ extern "C" int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, in
     }
     hipError_t e = hipMemsetAsync(workspace, 0, ctrl, (hipStream_t)stream);
     NTK_REQUIRE(e == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    if (dnc_cluster_is_fix(a.c) && !getenv("NTK_DNC_BWD_GENERIC")) dnc_cluster_bwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
+#ifdef NTK_DNC_BWD_GENERIC                                                  // dev build: the benchmark shape through the generic instantiation
+    const bool use_fix = false;
+#else
+    const bool use_fix = dnc_cluster_is_fix(a.c);
+#endif
+    if (use_fix) dnc_cluster_bwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     else dnc_cluster_bwd_kernel<false><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     NTK_CHECK_LAUNCH("ntk_dnc_cluster_bwd");
     return NTK_OK;

@@ -492,8 +492,11 @@ extern "C" int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int h
     NtmLds L;
     ntm_fwd_lds(a.d, T, L);
     const bool fixdims = (N == 128 && Md == 20 && R == 4 && Wh == 1 && hid == 200 && shift_range == 1 && O == 2);
-    const char* ev = getenv("NTK_NTM_FWD_VARIANT");                      // dev switch: 0 = the all-streaming 640-thread specialisation
-    const int variant = fixdims ? (ev ? atoi(ev) : 1) : 0;
+#ifdef NTK_NTM_FWD_STREAM_ONLY                                              // dev build: the all-streaming 640-thread specialisation of round 1
+    const int variant = 0;
+#else
+    const int variant = fixdims ? 1 : 0;
+#endif
     if (variant == 1) { T = 512; ntm_fwd_lds(a.d, T, L); }
     size_t lds_bytes = (size_t)L.total * sizeof(float) + 128;                    // + the diagnostic build's stamp words
     if (variant == 1) lds_bytes += (size_t)20 * 2 * hid * sizeof(f32x4);
