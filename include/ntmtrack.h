@@ -90,6 +90,13 @@ size_t ntk_vgg_wino43_packed_floats(int cin, int cout);
 int ntk_vgg_pack_weights_wino43(const float* w_hwio, float* u_packed, int cin, int cout, void* stream);
 int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                     int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream);
+/* The same layer computed only inside the window [y0, y1) x [x0, x1) of its un-pooled output (multiples of 4 inside the
+ * frame): the tiles of the window are written exactly as the whole-frame call writes them, nothing else is touched.  For
+ * the last layer of a trunk whose consumer reads fixed positions only (direct_offset_output.py:392-399 gathers 64 points
+ * of conv4_3, receptive_field_sizes.py:135-143: rows / columns 6, 8, ..., 20 of 28). */
+int ntk_vgg_conv3x3_relu_wino43_window_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                           int frames, int H, int W, int cin, int cout, int fuse_pool,
+                                           int y0, int x0, int y1, int x1, void* stream);
 
 /* slim.max_pool2d [2,2] stride 2 on NHWC fp32 (vgg.py:155-161) as its own launch (ntk_maxpool2x2).
  * The trunk fuses the pool into the epilogue of conv1_2 / conv2_2 / conv3_3 (fuse_pool); this entry point is the

@@ -66,7 +66,8 @@ struct Wino43Args {
     const float* in; const float* U; const float* bias; float* out;
     int frames, H, W, Cin, Cout;
     int nCB;            // Cout / 64
-    int bxN, byN;       // sub-blocks per frame: W/(4 TW), H/(4 TH)
+    int bxN, byN;       // sub-blocks per frame (of the computed window): W/(4 TW), H/(4 TH) for the whole frame
+    int bx0, by0;       // first sub-block column / row of the window (0: whole frame)
     int NS;             // workgroups per column block = ceil(NQ / NSUB)
     int NQ;             // sub-blocks = frames * byN * bxN
 };
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (sq < a.NQ) {
             const int bx = sq % a.bxN;
             const int t1 = sq / a.bxN;
-            s_sbf[tid] = t1 / a.byN; s_sby[tid] = 4 * TH * (t1 % a.byN); s_sbx[tid] = 4 * TW * bx;
+            s_sbf[tid] = t1 / a.byN; s_sby[tid] = 4 * TH * (a.by0 + t1 % a.byN); s_sbx[tid] = 4 * TW * (a.bx0 + bx);
         } else {
             s_sbf[tid] = -1; s_sby[tid] = 0; s_sbx[tid] = 0;
         }
@@ -566,8 +567,8 @@ extern "C" int ntk_vgg_pack_weights_wino43(const float* w_hwio, float* u_packed,
     return NTK_OK;
 }
 
-extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_packed, const float* bias, float* out,
-                                               int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream) {
+static int wino43_launch(const float* in, const float* u_packed, const float* bias, float* out,
+                         int frames, int H, int W, int cin, int cout, int fuse_pool, int y0, int x0, int y1, int x1, void* stream) {
     NTK_REQUIRE(in && u_packed && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_wino43_f32: null pointer");
     NTK_REQUIRE(ntk_aligned16(in) && ntk_aligned16(u_packed) && ntk_aligned16(out), NTK_ERR_BAD_PTR,
                 "ntk_vgg_conv3x3_relu_wino43_f32: 16-byte alignment");
@@ -583,12 +584,18 @@ extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_p
     a.in = in; a.U = u_packed; a.bias = bias; a.out = out;
     a.frames = frames; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
     // tile-block shape: 0 = 8x4x1 (tile grid multiple of 8 x 4), 1 = 4x4x2, 2 = 2x2x8, 3 = 1x1x32 (any grid)
-    const int gw = W / 4, gh = H / 4;
-    const int shape = ((gw % 8) == 0 && (gh % 4) == 0) ? 0 : (((gw % 4) == 0 && (gh % 4) == 0) ? 1 : (((gw % 2) == 0 && (gh % 2) == 0) ? 2 : 3));
+    // the computed window [y0, y1) x [x0, x1) in output pixels before the pool (whole frame: 0, 0, H, W), multiples of 4
+    NTK_REQUIRE(y0 >= 0 && x0 >= 0 && y1 <= H && x1 <= W && y0 < y1 && x0 < x1 && ((y0 | x0 | y1 | x1) & 3) == 0, NTK_ERR_BAD_SHAPE,
+                "ntk_vgg_conv3x3_relu_wino43: window [%d,%d) x [%d,%d) of a %d x %d frame (multiples of 4 inside the frame)", y0, y1, x0, x1, H, W);
+    const int gw = (x1 - x0) / 4, gh = (y1 - y0) / 4, gx0 = x0 / 4, gy0 = y0 / 4;
+    auto fits = [&](int tw, int th) { return (gw % tw) == 0 && (gh % th) == 0 && (gx0 % tw) == 0 && (gy0 % th) == 0; };
+    const int shape = fits(8, 4) ? 0 : (fits(4, 4) ? 1 : (fits(2, 2) ? 2 : 3));
     static const int TWs[4] = {8, 4, 2, 1}, THs[4] = {4, 4, 2, 1}, NSUBs[4] = {1, 2, 8, 32};
     a.nCB = cout / 64;
     a.bxN = gw / TWs[shape];
     a.byN = gh / THs[shape];
+    a.bx0 = gx0 / TWs[shape];
+    a.by0 = gy0 / THs[shape];
     const long long NQ = (long long)frames * a.byN * a.bxN;
     const long long NS = (NQ + NSUBs[shape] - 1) / NSUBs[shape];
     NTK_REQUIRE(NS < (1ll << 30) && (a.nCB <= 8 ? (8 % a.nCB) == 0 : (a.nCB % 8) == 0), NTK_ERR_UNSUPPORTED,
@@ -611,4 +618,19 @@ extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_p
 #undef W43_LAUNCH
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_wino43_f32");
     return NTK_OK;
+}
+
+extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                               int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream) {
+    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, 0, 0, H, W, stream);
+}
+
+// The same layer computed only inside the window [y0, y1) x [x0, x1) of the (un-pooled) output, multiples of 4: every 4x4 output
+// tile of the window is written exactly as the whole-frame call writes it, nothing outside the window is touched.  For the last
+// layer of a trunk whose consumer reads a fixed set of positions (extract_features' 64 points of conv4_3 lie in rows / columns
+// 4..23 of 28: 25 of the 49 tiles).
+extern "C" int ntk_vgg_conv3x3_relu_wino43_window_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                                      int frames, int H, int W, int cin, int cout, int fuse_pool,
+                                                      int y0, int x0, int y1, int x1, void* stream) {
+    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, y0, x0, y1, x1, stream);
 }

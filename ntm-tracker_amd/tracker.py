@@ -156,7 +156,8 @@ class _TwoStreamPipeline(object):
             raise _lib.NtkError("submit_features: two feature batches already outstanding")
         F = frames.shape[0]
         if not self._slots:
-            self._slots = [dict(buf=torch.empty((F, frames.shape[1] // 8, frames.shape[2] // 8, 512), device=self.device),
+            alloc = torch.zeros if getattr(self, "features_roi", False) else torch.empty      # outside the window the map stays zero
+            self._slots = [dict(buf=alloc((F, frames.shape[1] // 8, frames.shape[2] // 8, 512), device=self.device),
                                 free=None) for _ in range(2)]
         slot = self._slots[self._next_slot]          # strict alternation: never the buffer the core pass may still be reading
         self._next_slot ^= 1
@@ -203,11 +204,16 @@ class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  num_layers=1, read_head_size=4, write_head_size=1, write_first=False, init_scale=0.05,
                  learning_rate=1e-4, decay=0.95, momentum=0.9, max_gradient_norm=5.0, feature_channels=512,
-                 device="cuda", seed=42, vgg_chunk_frames=1024, conv_dtype="f32", conv_algo="winograd"):
+                 device="cuda", seed=42, vgg_chunk_frames=1024, conv_dtype="f32", conv_algo="winograd", features_roi=False):
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
         self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
+        self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and conv_algo == "winograd"
+        if self.features_roi:          # conv4_3 only where extract_features reads it (GRID_START .. GRID_START + (GRID_N - 1) * GRID_STEP), whole 4x4 tiles
+            lo = (GRID_START // 4) * 4
+            hi = ((GRID_START + (GRID_N - 1) * GRID_STEP) // 4 + 1) * 4
+            self.vgg.features_window = (lo, lo, hi, hi)
         self.cell = NTMCell(2, mem_size=mem_size, mem_dim=mem_dim, controller_hidden_size=hidden_size,
                             controller_num_layers=num_layers, write_head_size=write_head_size,
                             read_head_size=read_head_size, write_first=write_first,
@@ -273,12 +279,17 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  read_head_size=4, write_head_size=1, clip_value=20, feature_channels=512, device="cuda", seed=42,
                  vgg_chunk_frames=1024, learning_rate=1e-4, optimizer_epsilon=1e-10, max_gradient_norm=50.0,
-                 conv_dtype="f32", conv_algo="winograd"):
+                 conv_dtype="f32", conv_algo="winograd", features_roi=False):
         from .dnc import DNC
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
         self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
+        self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and conv_algo == "winograd"
+        if self.features_roi:          # conv4_3 only where extract_features reads it (GRID_START .. GRID_START + (GRID_N - 1) * GRID_STEP), whole 4x4 tiles
+            lo = (GRID_START // 4) * 4
+            hi = ((GRID_START + (GRID_N - 1) * GRID_STEP) // 4 + 1) * 4
+            self.vgg.features_window = (lo, lo, hi, hi)
         self.core = DNC({"memory_size": mem_size, "word_size": mem_dim, "num_reads": read_head_size,
                          "num_writes": write_head_size}, {"hidden_size": hidden_size}, 2, clip_value,
                         input_dim=feature_channels + 2, device=self.device, seed=seed)

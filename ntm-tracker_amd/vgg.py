@@ -109,14 +109,21 @@ def pack_weights_wino43(w_hwio):
     return u
 
 
-def conv3x3_relu_wino43(x, u_packed, bias, cin, cout, fuse_pool=False, out=None):
-    """Same operator as conv3x3_relu by fused Winograd F(4x4,3x3) (csrc/conv_wino43.hip)."""
+def conv3x3_relu_wino43(x, u_packed, bias, cin, cout, fuse_pool=False, out=None, window=None):
+    """Same operator as conv3x3_relu by fused Winograd F(4x4,3x3) (csrc/conv_wino43.hip).
+    window = (y0, x0, y1, x1), multiples of 4: compute only that part of the un-pooled output (the rest of `out` is not touched)."""
     F, H, W, C = x.shape
     if C != cin:
         raise _lib.NtkError("conv3x3_relu_wino43: input has %d channels, layer expects %d" % (C, cin))
     oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
     if out is None:
         out = torch.empty((F, oh, ow, cout), device=x.device, dtype=torch.float32)
+    if window is not None:
+        y0, x0, y1, x1 = [int(v) for v in window]
+        _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_wino43_window_f32(_lib.ptr(x), _lib.ptr(u_packed), _lib.ptr(bias), _lib.ptr(out),
+                                                                     F, H, W, cin, cout, 1 if fuse_pool else 0, y0, x0, y1, x1,
+                                                                     _lib.stream()), "ntk_vgg_conv3x3_relu_wino43_window_f32")
+        return out
     _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_wino43_f32(_lib.ptr(x), _lib.ptr(u_packed), _lib.ptr(bias), _lib.ptr(out),
                                                           F, H, W, cin, cout, 1 if fuse_pool else 0, _lib.stream()),
                "ntk_vgg_conv3x3_relu_wino43_f32")
@@ -161,6 +168,11 @@ class VGG16Conv43(object):
         if algo not in ("winograd", "winograd2", "direct"):
             raise _lib.NtkError("VGG16Conv43: algo must be 'winograd', 'winograd2' or 'direct'")
         self.dtype = dtype
+        # (y0, x0, y1, x1) in conv4_3 output pixels, multiples of 4, or None: compute conv4_3 only there (F(4x4) fp32 trunk).  The
+        # tracker's extract_features reads 64 fixed points of the 28x28 map (rows / columns 6..20): window (4, 4, 24, 24) = 25
+        # of its 49 tiles.  Positions outside the window keep whatever the buffer held (pass a zeroed `out`).  Off by default:
+        # the benchmark computes the whole map, as the reference graph does.
+        self.features_window = None
         # parts / streams of a trunk pass (see __call__): two for the default F(4x4) fp32 trunk; measured a loss for the direct
         # kernels (149 -> 173 ms per step) and for the bf16 trunk (59.5 -> 59.9), no change for F(2x2)
         self.split_streams = int(os.environ.get("NTK_TRUNK_SPLIT", "2" if (dtype == "f32" and algo == "winograd") else "1"))
@@ -211,8 +223,11 @@ class VGG16Conv43(object):
             wp, b = self.packed[name]
             last = (name == upto)
             if name in self.packed_wino43 and wino43_supported(cin, cout, x.shape[1], x.shape[2], x.shape[0]):
+                win = self.features_window if (last and name == "conv4_3") else None
+                if win is not None and out is None:
+                    out = torch.zeros((x.shape[0], x.shape[1], x.shape[2], cout), device=x.device, dtype=torch.float32)
                 x = conv3x3_relu_wino43(x, self.packed_wino43[name], b, cin, cout, fuse_pool=(pool and not last),
-                                        out=out if last else None)
+                                        out=out if last else None, window=win)
             elif name in self.packed_wino and wino_supported(cin, cout, x.shape[1], x.shape[2], x.shape[0]):
                 x = conv3x3_relu_wino(x, self.packed_wino[name], b, cin, cout, fuse_pool=(pool and not last),
                                       out=out if last else None)

@@ -243,6 +243,55 @@ def test_vgg_trunk_winograd_equals_direct_fullsize(cuda):
     assert _rel(y4, yd) < 2e-5
 
 
+def test_winograd43_window_equals_whole_frame_inside_and_touches_nothing_outside(cuda):
+    """ntk_vgg_conv3x3_relu_wino43_window_f32: the tiles of the window are bit-identical to the whole-frame call, every
+    position outside keeps the buffer's previous content; windows that select each tile-block shape; bad windows refused."""
+    from ntmtrack import vgg, _lib
+    rng = np.random.default_rng(12)
+    for (F, H, W, cin, cout, win) in [(3, 28, 28, 32, 64, (4, 4, 24, 24)),      # conv4_3's case: 5 x 5 of 7 x 7 tiles, 1x1x32 blocks
+                                      (2, 32, 32, 16, 64, (8, 16, 24, 32)),      # 4 x 4 tiles at even offsets: 2x2x8 blocks
+                                      (2, 64, 64, 16, 128, (16, 0, 48, 32)),     # 8 wide, 8 high at multiples of (8, 4) tiles: 8x4x1 blocks
+                                      (1, 20, 12, 16, 64, (0, 4, 20, 8))]:
+        x = torch.from_numpy(rng.standard_normal((F, H, W, cin)).astype(np.float32)).to(cuda)
+        w = torch.from_numpy((rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)).to(cuda)
+        b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(cuda)
+        up = vgg.pack_weights_wino43(w)
+        full = vgg.conv3x3_relu_wino43(x, up, b, cin, cout)
+        out = torch.full_like(full, -7.0)
+        vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=win)
+        y0, x0, y1, x1 = win
+        mask = torch.zeros((H, W), dtype=torch.bool, device=cuda)
+        mask[y0:y1, x0:x1] = True
+        assert torch.equal(out[:, mask], full[:, mask]), win
+        assert bool((out[:, ~mask] == -7.0).all()), win
+    with pytest.raises(_lib.NtkError):
+        vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=(0, 2, 20, 8))      # not a multiple of 4
+    with pytest.raises(_lib.NtkError):
+        vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=(0, 4, 24, 8))      # outside the frame
+
+
+def test_tracker_features_roi_is_invisible_to_the_recurrent_core(cuda):
+    """features_roi=True computes conv4_3 only where extract_features reads it: the serialised NTM input, the loss and the
+    gradients are bit-identical to the whole-map tracker's."""
+    from ntmtrack import tracker
+    rng = np.random.default_rng(13)
+    ws = O.init_vgg_weights(rng)
+    B, T = 2, 2
+    frames = torch.from_numpy((rng.uniform(0, 255, size=(B * T, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)).to(cuda)
+    gts0 = torch.from_numpy(rng.uniform(0, 1, size=(B, 64)).astype(np.float32)).to(cuda)
+    offs = torch.from_numpy(rng.uniform(-0.5, 0.5, size=(B, T, 2)).astype(np.float32)).to(cuda)
+    res = []
+    for roi in (False, True):
+        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=cuda, seed=3, features_roi=roi)
+        assert trk.features_roi == roi and (trk.vgg.features_window == (4, 4, 24, 24)) == roi
+        fmap = trk.vgg(frames)
+        X = trk.serialize(fmap, gts0)
+        loss, _ = trk.loss_and_grads(fmap, gts0, offs)
+        res.append((X.clone(), float(loss.cpu()), trk._flat_grad().clone(), fmap.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
+    assert not torch.equal(res[0][3], res[1][3])          # the maps themselves differ outside the window (zeros there)
+
+
 def test_vgg_trunk_stream_parts_do_not_change_the_result(cuda):
     """The default trunk runs a pass as two half batches on two streams (they fill each other's launch tails): the
     features are bit-identical to a one-stream pass and to a three-part pass, on the caller's current stream and on a side
