@@ -267,7 +267,7 @@ class DNC(object):
     #: per-sequence-step record budget above which a recorded pass switches to segmented BPTT (bytes).  Config 5
     #: (N=512: 1 MiB of link per step and sequence, 3250 steps) cannot keep every step: the forward pass then keeps
     #: one state checkpoint per segment and backward_sequence re-records segment by segment, last to first.
-    record_budget_bytes = 24 << 30
+    record_budget_bytes = 96 << 30      # a third of an MI355X's 288 GB: two record sets may be alive at a time (allocator caching)
     #: steps per BPTT segment; None = derive from record_budget_bytes (whole sequence when it fits)
     bptt_segment = None
     last_record = None
@@ -386,14 +386,18 @@ class DNC(object):
         xp = xproj.view(B, S, 4 * self.hid)
         out = torch.empty((B, S, self.O), device=self.device)
         ckpt, bounds = [], []
+        last_rec = {}
         for s0 in range(0, S, seg):
             s1 = min(S, s0 + seg)
             ckpt.append(st)
             bounds.append((s0, s1))
-            o, st = self._launch_fwd(xp[:, s0:s1].contiguous().view(B * (s1 - s0), 4 * self.hid), B, s1 - s0, st, {})
+            # the LAST segment is recorded right here: BPTT starts with it, so it never needs a second forward pass
+            rec = self._alloc_records(B, s1 - s0) if s1 == S else {}
+            o, st = self._launch_fwd(xp[:, s0:s1].contiguous().view(B * (s1 - s0), 4 * self.hid), B, s1 - s0, st, rec)
             out[:, s0:s1] = o
+            last_rec = rec
         self.last_record = {}
-        self.last_segments = (xp, ckpt, bounds)
+        self.last_segments = (xp, ckpt, bounds, last_rec)
         return out.transpose(0, 1), self._strip_state(st)
 
     def _launch_bwd(self, B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, gcarry, carry_in):
@@ -459,13 +463,17 @@ class DNC(object):
             dgates, dxi, dypre = self._launch_bwd(B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, None, False)
             self._weight_grads(X.view(B * S, self.ldx), rec, dgates, dxi, dypre, B * S, False)
             return self._unpack(grad=True)
-        xp, ckpt, bounds = self.last_segments
+        xp, ckpt, bounds, last_rec = self.last_segments
         gcarry = torch.zeros((B, (self.Wn + 1) * self.N + self.R * self.N + ldkT + hid), device=dev)
         first = True
         for st, (s0, s1) in zip(reversed(ckpt), reversed(bounds)):
             n = s1 - s0
-            rec = self._alloc_records(B, n)
-            self._launch_fwd(xp[:, s0:s1].contiguous().view(B * n, 4 * hid), B, n, st, rec)
+            if first and last_rec:
+                rec, last_rec = last_rec, None                     # recorded by the forward pass itself
+                self.last_segments = (xp, ckpt, bounds, None)      # consumed: a second backward call re-records it
+            else:
+                rec = self._alloc_records(B, n)
+                self._launch_fwd(xp[:, s0:s1].contiguous().view(B * n, 4 * hid), B, n, st, rec)
             dgates, dxi, dypre = self._launch_bwd(B, n, st, rec, dout[:, s0:s1].contiguous(), WrT, ldkT, WiT, ldhT, gM, gL,
                                                   gcarry, not first)
             self._weight_grads(X[:, s0:s1].contiguous().view(B * n, self.ldx), rec, dgates, dxi, dypre, B * n, not first)
