@@ -257,8 +257,17 @@ class DNC(object):
 
     REC_NAMES = ("z", "gates", "c", "hc", "yin", "ifc", "u", "ww", "rw", "cw", "cr", "al", "p", "fwd", "bwd", "M", "L", "ypre")
 
-    def _alloc_records(self, B, S):
-        e = lambda *s: torch.empty((B, S) + s, device=self.device)
+    def _alloc_records(self, B, S, cap=None):
+        """Record tensors [B, S, ...].  cap >= S: allocate room for cap steps and return the leading [B, S, ...] part -- segmented
+        BPTT asks for its (equal) segment length every time, so that a freed set's blocks fit the next set exactly (a 70 GB
+        block does not serve a 73.5 GB request, and config 5 has no room for a third link record)."""
+        cap = max(S, cap or S)
+
+        def e(*s):
+            n = 1
+            for v in s:
+                n *= v
+            return torch.empty((B * cap * n,), device=self.device)[:B * S * n].view((B, S) + s)
         N, W, R, Wn, hid = self.N, self.W, self.R, self.Wn, self.hid
         return {"z": e(self.ldz), "gates": e(hid, 4), "c": e(hid), "hc": e(self.ldh), "yin": e(self.ldy), "ifc": e(self.IP),
                 "u": e(N), "ww": e(Wn, N), "rw": e(R, N), "cw": e(Wn, N), "cr": e(R, N), "al": e(Wn, N), "p": e(Wn, N),
@@ -272,6 +281,7 @@ class DNC(object):
     bptt_segment = None
     last_record = None
     last_segments = None
+    _rerec_stream = None
     last_initial = None
 
     def _record_floats_per_step(self):
@@ -392,12 +402,12 @@ class DNC(object):
             ckpt.append(st)
             bounds.append((s0, s1))
             # the LAST segment is recorded right here: BPTT starts with it, so it never needs a second forward pass
-            rec = self._alloc_records(B, s1 - s0) if s1 == S else {}
+            rec = self._alloc_records(B, s1 - s0, cap=seg) if s1 == S else {}
             o, st = self._launch_fwd(xp[:, s0:s1].contiguous().view(B * (s1 - s0), 4 * self.hid), B, s1 - s0, st, rec)
             out[:, s0:s1] = o
             last_rec = rec
         self.last_record = {}
-        self.last_segments = (xp, ckpt, bounds, last_rec)
+        self.last_segments = (xp, ckpt, bounds, last_rec, seg)
         return out.transpose(0, 1), self._strip_state(st)
 
     def _launch_bwd(self, B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, gcarry, carry_in):
@@ -463,22 +473,48 @@ class DNC(object):
             dgates, dxi, dypre = self._launch_bwd(B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, None, False)
             self._weight_grads(X.view(B * S, self.ldx), rec, dgates, dxi, dypre, B * S, False)
             return self._unpack(grad=True)
-        xp, ckpt, bounds, last_rec = self.last_segments
+        xp, ckpt, bounds, last_rec, seg_cap = self.last_segments
         gcarry = torch.zeros((B, (self.Wn + 1) * self.N + self.R * self.N + ldkT + hid), device=dev)
+        # Last segment first.  The re-recording forward pass of segment s - 1 depends only on its checkpoint, so it runs on a
+        # side stream (other CUs: these kernels hold one CU per sequence) WHILE segment s is back-propagated: the second forward
+        # pass disappears behind the longer backward pass.  Two record sets are alive at a time (record_budget_bytes).
+        cur = torch.cuda.current_stream(dev)
+        if self._rerec_stream is None:
+            self._rerec_stream = torch.cuda.Stream(device=dev)
+        side = self._rerec_stream
+        segs = list(zip(reversed(ckpt), reversed(bounds)))
+
+        def rerecord(k):
+            st_k, (a0, a1) = segs[k]
+            # records come from THIS stream's allocator pool (a freed set is reused two segments later; pools are per stream:
+            # allocating on the side stream kept three sets alive and ran out of HBM at config 5); the side stream orders
+            # itself after everything enqueued here, which includes the last reader of the memory being reused
+            r = self._alloc_records(B, a1 - a0, cap=seg_cap)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._launch_fwd(xp[:, a0:a1].contiguous().view(B * (a1 - a0), 4 * hid), B, a1 - a0, st_k, r)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return r, ev
+
+        if last_rec:
+            pending = (last_rec, None)                             # recorded by the forward pass itself
+            last_rec = None                                        # (no second reference: the set must die with its segment)
+            self.last_segments = (xp, ckpt, bounds, None, seg_cap)     # consumed: a second backward call re-records it
+        else:
+            pending = rerecord(0)
         first = True
-        for st, (s0, s1) in zip(reversed(ckpt), reversed(bounds)):
+        for k, (st, (s0, s1)) in enumerate(segs):
             n = s1 - s0
-            if first and last_rec:
-                rec, last_rec = last_rec, None                     # recorded by the forward pass itself
-                self.last_segments = (xp, ckpt, bounds, None)      # consumed: a second backward call re-records it
-            else:
-                rec = self._alloc_records(B, n)
-                self._launch_fwd(xp[:, s0:s1].contiguous().view(B * n, 4 * hid), B, n, st, rec)
+            rec, ev = pending
+            pending = rerecord(k + 1) if k + 1 < len(segs) else None
+            if ev is not None:
+                cur.wait_event(ev)
             dgates, dxi, dypre = self._launch_bwd(B, n, st, rec, dout[:, s0:s1].contiguous(), WrT, ldkT, WiT, ldhT, gM, gL,
                                                   gcarry, not first)
             self._weight_grads(X[:, s0:s1].contiguous().view(B * n, self.ldx), rec, dgates, dxi, dypre, B * n, not first)
             first = False
-            del rec
+            del rec                                                # freed in this stream's order: after its last reader
         return self._unpack(grad=True)
 
     def __call__(self, inputs, prev_state):
