@@ -34,7 +34,7 @@ TRUNK_TRAFFIC_PROFILE = {"direct": "profiles/r01_vgg_trunk_hbm_traffic_pmc.csv",
 # fraction of the direct-convolution multiplies the Winograd layers execute on the MFMA pipe: F(2x2,3x3) 16 per 2x2 tile
 # where the direct form has 36; F(4x4,3x3) 36 per 4x4 tile where it has 144
 WINO_EXECUTED_FRACTION = {"winograd": 36.0 / 144.0, "winograd2": 16.0 / 36.0}
-NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.451e8 + 1.036e9     # profiles/r01_ntm_seq_hbm_traffic_pmc.csv
+NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.445e8 + 1.036e9     # profiles/r02_ntm_seq_hbm_traffic_pmc.csv
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
@@ -157,7 +157,7 @@ def cpu_baseline(ws, n_vgg_frames=8, T=20, model="ntm", dnc_shape=(256, 64)):
 # HBM-side bytes of the DNC cluster kernels at configs[2] (B 32, S 1300): profiles/r02_dnc_cluster_hbm_traffic_pmc.csv
 DNC_FWD_TRAFFIC_BYTES_B32_S1300 = 4.56e9        # inference-mode forward (2 x FETCH_SIZE + WRITE_SIZE)
 DNC_BWD_TRAFFIC_BYTES_B32_S1300 = 2.123e10
-NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.95e9 + 0.16e9   # profiles/r01_ntm_seq_hbm_traffic_pmc.csv
+NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.950e9 + 0.162e9   # profiles/r02_ntm_seq_hbm_traffic_pmc.csv
 
 
 def _median_ms(fn, n=3):
@@ -195,7 +195,7 @@ def memory_step_probe(trk, model, gts0, offs, B, T):
         traffic = NTM_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)
         traffic_b = NTM_BWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)
         note = "serialise + input projection + persistent sequence kernel, one workgroup per sequence; state is LDS resident"
-        tnote = "PMC, profiles/r01_ntm_seq_hbm_traffic_pmc.csv: input projection read + per-step BPTT records; the memory state itself never leaves LDS"
+        tnote = "PMC, profiles/r02_ntm_seq_hbm_traffic_pmc.csv: input projection read + per-step BPTT records; the memory state itself never leaves LDS"
     else:
         c = trk.core
         per_step = 2 * c.N * c.W * 4 + 2 * c.Wn * c.N * c.N * 4 + 2 * (c.R + c.Wn) * c.N * 4 + 2 * c.Wn * c.N * 4 + 2 * c.N * 4
