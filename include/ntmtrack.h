@@ -280,6 +280,31 @@ int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int 
                         const float* dout, float* gM, float* gL, float* dgates, float* dxi, float* dypre,
                         float* gcarry, int carry_in, void* workspace, void* stream);
 
+/* The sequence kernels in MEMORY-PARTITIONED cluster form (csrc/dnc_mp.h): k workgroups per sequence, the N x N link
+ * streamed through HBM once per step (N/k rows per workgroup; the BPTT record of step t-1 is the state step t reads),
+ * the N x W memory partitioned by rows (LDS resident forward, register resident in BPTT), per-slot state replicated, four
+ * hand-offs per step.  Nothing of size N x N or N x W is replicated, so this is the form for BASELINE configs[4]'s
+ * core (memory 512 x 128: dnc/addressing.py:183-240 on 1 MiB of link per sequence-step), which the LDS-resident form
+ * above cannot hold.  Same arguments, in-place state semantics and records as ntk_dnc_seq_fwd / ntk_dnc_seq_bwd; results
+ * differ by summation order only and are bitwise reproducible run to run.
+ * ntk_dnc_mp_plan / ntk_dnc_mp_bwd_plan: cluster size (k_request 0 = the smallest that fits; B * k <= the device's compute
+ * units, queried per device) and the workspace size.  The workspace is caller-owned, 16-byte aligned, ZEROED ONCE by its
+ * owner: besides the per-launch control words (re-zeroed by every launch) its last 256-byte line holds a STICKY error
+ * word that a timed-out hand-off sets and no launch clears.  ntk_dnc_mp_status synchronises `stream` and fails when the
+ * last launch or (sticky word) any launch since the word was last cleared aborted; clear_sticky != 0 clears it. */
+int ntk_cu_count(void);
+int ntk_dnc_mp_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes);
+int ntk_dnc_mp_status(const void* workspace, size_t workspace_bytes, int B, int k, int clear_sticky, void* stream);
+int ntk_dnc_mp_placement(const void* workspace, int B, int k, int* same_xcd_clusters, void* stream);
+int ntk_dnc_mp_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value, int k,
+                   const float* xproj, const float* Wr, const float* Wi, const float* Wy,
+                   float* mem, float* link, float* usage, float* rw, float* ww, float* prec,
+                   float* reads, float* hc, float* out,
+                   float* rec_z, float* rec_gates, float* rec_c, float* rec_hc, float* rec_yin,
+                   float* rec_ifc, float* rec_u, float* rec_ww, float* rec_rw, float* rec_cw,
+                   float* rec_cr, float* rec_al, float* rec_p, float* rec_fwd, float* rec_bwd,
+                   float* rec_M, float* rec_L, float* rec_ypre, void* workspace, void* stream);
+
 /* Stand-alone DNC addressing modules (dnc/addressing.py), the module-level API the reference's own tests call:
  * CosineWeights._build (:83-105), TemporalLinkage._build (:133-153) and directional_read_weights (:155-181),
  * Freeness._build (:279-305) and write_allocation_weights (:307-340; one head: _allocation :376-405). */

@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void ntk_set_error(const char* fmt, ...);
+int ntk_device_cu_count();      // api.cpp: compute units of the current device (cached per device)
 
 #define NTK_REQUIRE(cond, code, ...)                 \
     do {                                             \

@@ -747,7 +747,7 @@ static int dnc_cluster_pick(int B, int N, int W, int R, int Wn, int hid, int O, 
         return 0;
     for (int k = 8; k >= 1; k >>= 1) {
         if (k_req > 0 && k != k_req) continue;
-        if ((long)B * k > 256) continue;                       // one workgroup per CU, all co-resident
+        if ((long)B * k > ntk_device_cu_count()) continue;     // one workgroup per CU, all co-resident (api.cpp)
         const int NR = N / k;
         if (NR * k != N || NR < 8 || (NR % 8) != 0) continue;
         c = dnc_cluster_cfg(N, W, R, hid, O, k);

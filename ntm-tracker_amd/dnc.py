@@ -300,57 +300,75 @@ class DNC(object):
     cluster_k = None
     _cluster = None
 
-    def _cluster_plan(self, B):
-        """(k, workspace tensor) for the cluster kernels at batch B, or None when the shape is outside their range."""
+    #: which cluster form may run: None = automatic (the LDS-resident form when the shape fits it, else the memory-partitioned
+    #: form), "lds" = only ntk_dnc_cluster_*, "mp" = only ntk_dnc_mp_* (csrc/dnc_mp.h).  NTK_DNC_CLUSTER_FORM overrides the default.
+    cluster_form = None
+
+    def _want(self):
         import os
         want = self.cluster_k
         if want is None and os.environ.get("NTK_DNC_CLUSTER_K"):
             want = int(os.environ["NTK_DNC_CLUSTER_K"])
+        form = self.cluster_form or os.environ.get("NTK_DNC_CLUSTER_FORM") or None
+        return want, form
+
+    def _plan(self, B, bwd):
+        """(form, k, workspace tensor, workspace bytes) of the cluster kernels at batch B, or None when neither form takes
+        the shape (then the one-workgroup-per-sequence kernels run)."""
+        want, form = self._want()
         if want == 0:
             return None
-        key = (B, want)
-        if self._cluster is None or self._cluster[0] != key:
-            k, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
-            rc = _lib.lib().ntk_dnc_cluster_plan(B, self.N, self.W, self.R, self.Wn, self.hid, self.O, int(want or 0),
-                                                 ctypes.byref(k), ctypes.byref(nbytes))
-            ws = torch.empty((nbytes.value + 3) // 4, device=self.device, dtype=torch.float32) if rc == 0 and k.value > 1 else None
-            self._cluster = (key, k.value if ws is not None else 0, ws)
-        return (self._cluster[1], self._cluster[2]) if self._cluster[1] > 1 else None
+        key = (B, want, form)
+        slot = "_cluster_b" if bwd else "_cluster"
+        cur = getattr(self, slot)
+        if cur is None or cur[0] != key:
+            L = _lib.lib()
+            found = None
+            for f, fn in (("lds", L.ntk_dnc_cluster_bwd_plan if bwd else L.ntk_dnc_cluster_plan),
+                          ("mp", getattr(L, "ntk_dnc_mp_bwd_plan", None) if bwd else L.ntk_dnc_mp_plan)):
+                if form not in (None, f) or fn is None:
+                    continue
+                k, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
+                rc = fn(B, self.N, self.W, self.R, self.Wn, self.hid, self.O, int(want or 0), ctypes.byref(k), ctypes.byref(nbytes))
+                if rc == 0 and k.value > 1:
+                    # zeroed ONCE here: the mp form keeps a sticky error word in the workspace that no launch clears
+                    ws = torch.zeros((nbytes.value + 3) // 4, device=self.device, dtype=torch.float32)
+                    found = (f, k.value, ws, nbytes.value)
+                    break
+            setattr(self, slot, (key, found))
+            cur = getattr(self, slot)
+        return cur[1]
+
+    def _cluster_plan(self, B):
+        return self._plan(B, False)
 
     _cluster_b = None
 
     def _cluster_bwd_plan(self, B):
-        """(k, workspace) for the cluster BPTT kernel at batch B, or None (then ntk_dnc_seq_bwd runs)."""
-        import os
-        want = self.cluster_k
-        if want is None and os.environ.get("NTK_DNC_CLUSTER_K"):
-            want = int(os.environ["NTK_DNC_CLUSTER_K"])
-        if want == 0:
-            return None
-        key = (B, want)
-        if self._cluster_b is None or self._cluster_b[0] != key:
-            k, nbytes = ctypes.c_int(0), ctypes.c_size_t(0)
-            rc = _lib.lib().ntk_dnc_cluster_bwd_plan(B, self.N, self.W, self.R, self.Wn, self.hid, self.O, int(want or 0),
-                                                     ctypes.byref(k), ctypes.byref(nbytes))
-            ws = torch.empty((nbytes.value + 3) // 4, device=self.device, dtype=torch.float32) if rc == 0 and k.value > 1 else None
-            self._cluster_b = (key, k.value if ws is not None else 0, ws)
-        return (self._cluster_b[1], self._cluster_b[2]) if self._cluster_b[1] > 1 else None
+        return self._plan(B, True)
 
-    def check_cluster(self):
-        """Synchronise and raise if a hand-off of the last cluster launches timed out (tests, end of a benchmark)."""
+    def check_cluster(self, clear=True):
+        """Synchronise and raise if a hand-off of the cluster launches timed out (the last launch; for the memory-partitioned
+        form ANY launch since the last check: its error word is sticky).  Called by the trackers where a training step
+        synchronises anyway, by the tests and at the end of a benchmark."""
         for c in (self._cluster, self._cluster_b):
-            if c is not None and c[1] > 1:
-                _lib.check(_lib.lib().ntk_dnc_cluster_status(_P(c[2]), c[0][0], c[1], _lib.stream()), "ntk_dnc_cluster_status")
+            if c is not None and c[1] is not None:
+                form, k, ws, nbytes = c[1]
+                if form == "lds":
+                    _lib.check(_lib.lib().ntk_dnc_cluster_status(_P(ws), c[0][0], k, _lib.stream()), "ntk_dnc_cluster_status")
+                else:
+                    _lib.check(_lib.lib().ntk_dnc_mp_status(_P(ws), nbytes, c[0][0], k, 1 if clear else 0, _lib.stream()), "ntk_dnc_mp_status")
 
     def cluster_placement(self):
         """(clusters that ran the same-XCD form of the hand-offs, clusters) of the last forward / BPTT cluster launches;
         a speed diagnostic only (csrc/dnc_cluster.h).  Synchronises."""
         out = []
         for c in (self._cluster, self._cluster_b):
-            if c is not None and c[1] > 1:
+            if c is not None and c[1] is not None:
+                form, k, ws, _nb = c[1]
                 n = ctypes.c_int(0)
-                _lib.check(_lib.lib().ntk_dnc_cluster_placement(_P(c[2]), c[0][0], c[1], ctypes.byref(n), _lib.stream()),
-                           "ntk_dnc_cluster_placement")
+                fn = _lib.lib().ntk_dnc_cluster_placement if form == "lds" else _lib.lib().ntk_dnc_mp_placement
+                _lib.check(fn(_P(ws), c[0][0], k, ctypes.byref(n), _lib.stream()), "ntk_dnc_cluster_placement")
                 out.append((n.value, c[0][0]))
         return out
 
@@ -366,12 +384,14 @@ class DNC(object):
         out = torch.empty((B, S, self.O), device=self.device)
         recp = [(_P(rec[k]) if rec else None) for k in self.REC_NAMES]
         plan = self._cluster_plan(B)
-        self.last_cluster_k = plan[0] if plan else 1
+        self.last_cluster_k = plan[1] if plan else 1
+        self.last_cluster_form = plan[0] if plan else None
         if plan:
-            _lib.check(_lib.lib().ntk_dnc_cluster_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value, plan[0],
-                                                      _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
-                                                      _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), *recp, _P(plan[1]),
-                                                      _lib.stream()), "ntk_dnc_cluster_fwd")
+            fn = _lib.lib().ntk_dnc_cluster_fwd if plan[0] == "lds" else _lib.lib().ntk_dnc_mp_fwd
+            _lib.check(fn(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value, plan[1],
+                          _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
+                          _P(rw), _P(ww), _P(prec), _P(reads), _P(hc), _P(out), *recp, _P(plan[2]),
+                          _lib.stream()), "ntk_dnc_cluster_fwd" if plan[0] == "lds" else "ntk_dnc_mp_fwd")
         else:
             _lib.check(_lib.lib().ntk_dnc_seq_fwd(B, S, self.N, self.W, self.R, self.Wn, self.hid, self.O, self.clip_value,
                                                   _P(xproj), _P(self.Wr), _P(self.Wi), _P(self.Wy), _P(mem), _P(link), _P(usage),
@@ -429,11 +449,13 @@ class DNC(object):
         state0 = (c(acc.memory), c(acc.linkage.link), c(acc.usage), c(acc.read_weights), c(acc.write_weights),
                   c(acc.linkage.precedence_weights), _P(hc0))
         plan = self._cluster_bwd_plan(B)
-        self.last_cluster_bwd_k = plan[0] if plan else 1
+        self.last_cluster_bwd_k = plan[1] if plan else 1
+        self.last_cluster_bwd_form = plan[0] if plan else None
         if plan:
-            _lib.check(_lib.lib().ntk_dnc_cluster_bwd(
-                B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value, plan[0],
-                _P(WrT), ldkT, _P(self.Wi), _P(self.Wy), *state0, *recs, _P(plan[1]), _lib.stream()), "ntk_dnc_cluster_bwd")
+            fn = _lib.lib().ntk_dnc_cluster_bwd if plan[0] == "lds" else _lib.lib().ntk_dnc_mp_bwd
+            _lib.check(fn(B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value, plan[1],
+                          _P(WrT), ldkT, _P(self.Wi), _P(self.Wy), *state0, *recs, _P(plan[2]), _lib.stream()),
+                       "ntk_dnc_cluster_bwd" if plan[0] == "lds" else "ntk_dnc_mp_bwd")
         else:
             _lib.check(_lib.lib().ntk_dnc_seq_bwd(
                 B, S, self.N, self.W, self.R, self.Wn, hid, self.O, self.clip_value,
