@@ -305,6 +305,18 @@ int ntk_dnc_mp_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, fl
                    float* rec_cr, float* rec_al, float* rec_p, float* rec_fwd, float* rec_bwd,
                    float* rec_M, float* rec_L, float* rec_ypre, void* workspace, void* stream);
 
+int ntk_dnc_mp_bwd_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes);
+int ntk_dnc_mp_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value, int k,
+                   const float* WrT, int ldkT, const float* Wi, const float* Wy,
+                   const float* mem0, const float* link0, const float* usage0, const float* rw0,
+                   const float* ww0, const float* prec0, const float* hc0,
+                   const float* rec_gates, const float* rec_c, const float* rec_ifc, const float* rec_u,
+                   const float* rec_ww, const float* rec_rw, const float* rec_cw, const float* rec_cr,
+                   const float* rec_al, const float* rec_p, const float* rec_fwd, const float* rec_bwd,
+                   const float* rec_M, const float* rec_L, const float* rec_ypre,
+                   const float* dout, float* gM, float* gL, float* dgates, float* dxi, float* dypre,
+                   float* gcarry, int carry_in, void* workspace, void* stream);
+
 /* Stand-alone DNC addressing modules (dnc/addressing.py), the module-level API the reference's own tests call:
  * CosineWeights._build (:83-105), TemporalLinkage._build (:133-153) and directional_read_weights (:155-181),
  * Freeness._build (:279-305) and write_allocation_weights (:307-340; one head: _allocation :376-405). */

@@ -51,6 +51,8 @@ def _sig(lib):
         "ntk_dnc_mp_status": (c_int, [P, c_size_t, c_int, c_int, c_int, P]),
         "ntk_dnc_mp_placement": (c_int, [P, c_int, c_int, P, P]),
         "ntk_dnc_mp_fwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P] * 13 + [P] * 18 + [P, P]),
+        "ntk_dnc_mp_bwd_plan": (c_int, [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
+        "ntk_dnc_mp_bwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P, c_int, P, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P, c_int, P, P]),
         "ntk_dnc_cosine_weights": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_dnc_linkage": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
         "ntk_dnc_directional_read_weights": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -11,7 +11,7 @@ SHAPES = [  # N, W, R, hid, B, S, k
     (64, 16, 2, 32, 2, 5, 2), (64, 16, 2, 32, 2, 5, 4), (64, 16, 2, 32, 3, 5, 8), (128, 32, 4, 64, 8, 6, 4),
     (256, 64, 4, 200, 8, 8, 4), (256, 64, 4, 200, 8, 8, 2), (512, 128, 4, 200, 8, 6, 4), (512, 128, 4, 200, 2, 40, 4),
 ]
-if len(sys.argv) > 1:
+if any("," in a for a in sys.argv[1:]):
     SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if "," in a]
 do_bwd = "--bwd" in sys.argv or os.environ.get("MP_BWD") == "1"
 
