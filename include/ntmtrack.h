@@ -246,8 +246,8 @@ int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, f
  * ntk_dnc_cluster_plan: the cluster size for a shape (k_request 0 = the largest that fits: B * k <= 256 CUs, link
  * rows + memory LDS resident; NTK_ERR_UNSUPPORTED and *k = 0 when the shape is outside the cluster kernels' range:
  * num_writes != 1, memory_size not a multiple of 64, ...) and the workspace size in bytes.  The workspace is
- * caller-owned device memory, 16-byte aligned, private to one launch at a time; its control words are re-zeroed by
- * every launch.  ntk_dnc_cluster_status synchronises `stream` and reports whether a hand-off of the last launch on
+ * caller-owned device memory, 16-byte aligned, ZEROED ONCE by its owner, private to one launch at a time; its control
+ * words are re-zeroed by every launch, its sticky error word (csrc/dnc_cluster.h) by ntk_dnc_cluster_status only.  ntk_dnc_cluster_status synchronises `stream` and reports whether a hand-off of the last launch on
  * that workspace timed out (every in-kernel spin is bounded; a launch that could not make progress aborts itself).
  * ntk_dnc_cluster_placement synchronises `stream` and reports how many of the B clusters of the last launch on that
  * workspace found all their k workgroups on one XCD and therefore ran the same-XCD form of the hand-offs (plain stores
@@ -255,6 +255,12 @@ int ntk_dnc_seq_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, f
 int ntk_dnc_cluster_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes);
 int ntk_dnc_cluster_status(const void* workspace, int B, int k, void* stream);
 int ntk_dnc_cluster_placement(const void* workspace, int B, int k, int* same_xcd_clusters, void* stream);
+/* Device-side propagation of an aborted cluster launch, without a host synchronisation: when the sticky error word of
+ * `workspace` (either form: mp_form 0 = ntk_dnc_cluster_*, 1 = ntk_dnc_mp_*, with its workspace_bytes) is set, loss[0]
+ * becomes NaN and grad[0..n) zero, so that the optimiser step enqueued behind it is harmless and the failure is visible
+ * to whoever reads the loss.  loss / grad may be null. */
+int ntk_dnc_cluster_guard(const void* workspace, size_t workspace_bytes, int mp_form, int B, int k, float* loss, float* grad,
+                          size_t n, void* stream);
 int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value, int k,
                         const float* xproj, const float* Wr, const float* Wi, const float* Wy,
                         float* mem, float* link, float* usage, float* rw, float* ww, float* prec,

@@ -43,6 +43,7 @@ def _sig(lib):
         "ntk_dnc_cluster_plan": (c_int, [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
         "ntk_dnc_cluster_status": (c_int, [P, c_int, c_int, P]),
         "ntk_dnc_cluster_placement": (c_int, [P, c_int, c_int, P, P]),
+        "ntk_dnc_cluster_guard": (c_int, [P, c_size_t, c_int, c_int, c_int, P, P, c_size_t, P]),
         "ntk_dnc_cluster_fwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P] * 13 + [P] * 18 + [P, P]),
         "ntk_dnc_cluster_bwd_plan": (c_int, [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
         "ntk_dnc_cluster_bwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P, c_int, P, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P, c_int, P, P]),

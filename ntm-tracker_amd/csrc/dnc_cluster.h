@@ -25,6 +25,8 @@
 #pragma once
 #include "dnc_common.h"
 
+void dnc_cluster_latch(const unsigned* err, unsigned* sticky, void* stream);      // dnc_cluster_fwd.hip
+
 constexpr int CT = 512;       // threads per cluster workgroup
 constexpr int CW = CT / 64;   // waves
 
@@ -223,9 +225,13 @@ static inline bool dnc_cluster_is_fix(const DncClusterCfg& c) {
     return c.N == 256 && c.W == 64 && c.R == 4 && c.hid == 200 && c.O == 2 && c.k == 8;
 }
 
-// control block of a launch: flags [B][2][k], the error word, the XCC words of the handshake [B][k]; padded to 256 bytes
-// (the mailbox follows); zeroed before EVERY launch
-static inline size_t dnc_cluster_ctrl_bytes(int B, int k) { return (((size_t)B * 3 * k + 1) * sizeof(unsigned) + 255) & ~(size_t)255; }
+// control block of a launch: flags [B][2][k], the error word, the XCC words of the handshake [B][k]; padded to 256 bytes and
+// zeroed before EVERY launch (dnc_cluster_ctrl_zero_bytes); then one more 256-byte line whose first word is the STICKY
+// error word: a one-thread latch kernel enqueued behind every launch ORs the launch's error word into it, no launch clears
+// it (the owner of the workspace zeroes it once), so an abort in an EARLIER launch of a multi-launch pass (segmented
+// forward, re-recording, BPTT) is still there when the caller looks.  The mailbox follows.
+static inline size_t dnc_cluster_ctrl_zero_bytes(int B, int k) { return (((size_t)B * 3 * k + 1) * sizeof(unsigned) + 255) & ~(size_t)255; }
+static inline size_t dnc_cluster_ctrl_bytes(int B, int k) { return dnc_cluster_ctrl_zero_bytes(B, k) + 256; }
 
 // mailbox layout (floats): per sequence [exchange][parity][g][slot]; flags (unsigned): per sequence [exchange][g]
 static inline size_t dnc_cluster_mbox_floats(int B, int k, int slot0, int slot1) {

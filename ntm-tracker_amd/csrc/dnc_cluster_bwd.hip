@@ -1146,7 +1146,7 @@ extern "C" int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, in
         const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 2, "ntk_dnc_cluster_bwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
-    hipError_t e = hipMemsetAsync(workspace, 0, ctrl, (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(workspace, 0, dnc_cluster_ctrl_zero_bytes(B, k), (hipStream_t)stream);
     NTK_REQUIRE(e == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
 #ifdef NTK_DNC_BWD_GENERIC                                                  // dev build: the benchmark shape through the generic instantiation
     const bool use_fix = false;
@@ -1156,5 +1156,7 @@ extern "C" int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, in
     if (use_fix) dnc_cluster_bwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     else dnc_cluster_bwd_kernel<false><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     NTK_CHECK_LAUNCH("ntk_dnc_cluster_bwd");
+    dnc_cluster_latch(a.err, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + ctrl - 256), stream);
+    NTK_CHECK_LAUNCH("ntk_dnc_cluster_bwd (latch)");
     return NTK_OK;
 }

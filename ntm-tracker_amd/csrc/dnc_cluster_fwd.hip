@@ -740,6 +740,32 @@ extern "C" int ntk_dnc_cluster_prof(unsigned long long* out16) {
 }
 #endif
 
+// one thread: OR the launch's error word into the workspace's sticky word (dnc_cluster.h)
+__global__ void dnc_cluster_latch_kernel(const unsigned* err, unsigned* sticky) { if (*err != 0u) *sticky = 1u; }
+void dnc_cluster_latch(const unsigned* err, unsigned* sticky, void* stream) {
+    dnc_cluster_latch_kernel<<<1, 1, 0, (hipStream_t)stream>>>(err, sticky);
+}
+
+// device-side propagation of an abort (no host synchronisation): when the sticky word of a workspace is set, the loss
+// becomes NaN and the gradient zero, so the optimiser step that follows is harmless and whoever reads the loss sees it
+__global__ void dnc_cluster_guard_kernel(const unsigned* sticky, float* loss, float* grad, size_t n) {
+    if (*sticky == 0u) return;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if (i0 == 0 && loss) loss[0] = __int_as_float(0x7fc00000);
+    if (grad) for (size_t i = i0; i < n; i += step) grad[i] = 0.f;
+}
+
+extern "C" int ntk_dnc_cluster_guard(const void* workspace, size_t workspace_bytes, int mp_form, int B, int k, float* loss, float* grad,
+                                     size_t n, void* stream) {
+    NTK_REQUIRE(workspace && B > 0 && k > 0, NTK_ERR_BAD_PTR, "ntk_dnc_cluster_guard: bad arguments");
+    const char* w = reinterpret_cast<const char*>(workspace);
+    const unsigned* stk = reinterpret_cast<const unsigned*>(mp_form ? w + workspace_bytes - 256 : w + dnc_cluster_ctrl_bytes(B, k) - 256);
+    NTK_REQUIRE(!mp_form || workspace_bytes >= 512, NTK_ERR_BAD_PTR, "ntk_dnc_cluster_guard: workspace_bytes");
+    dnc_cluster_guard_kernel<<<64, 256, 0, (hipStream_t)stream>>>(stk, loss, grad, grad ? n : 0);
+    NTK_CHECK_LAUNCH("ntk_dnc_cluster_guard");
+    return NTK_OK;
+}
+
 // the cluster size (0 = none) and configuration of a shape; k_req 0 = the largest k that fits
 static int dnc_cluster_pick(int B, int N, int W, int R, int Wn, int hid, int O, int k_req, DncClusterCfg& c, size_t* lds_bytes) {
     if (Wn != 1 || R < 1 || R > 4 || N < 64 || (N % 64) != 0 || N > CT || W < 4 || (W % 4) != 0 || W > 256 || hid < 4 ||
@@ -780,12 +806,16 @@ extern "C" int ntk_dnc_cluster_plan(int B, int N, int W, int R, int Wn, int hid,
 
 extern "C" int ntk_dnc_cluster_status(const void* workspace, int B, int k, void* stream) {
     NTK_REQUIRE(workspace && B > 0 && k > 0, NTK_ERR_BAD_PTR, "ntk_dnc_cluster_status: bad arguments");
-    unsigned e = 0;
+    unsigned e[2] = {0, 0};
     const unsigned* errw = reinterpret_cast<const unsigned*>(workspace) + (size_t)B * 2 * k;
-    hipError_t rc = hipMemcpyAsync(&e, errw, sizeof(e), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    unsigned* stk = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(const_cast<void*>(workspace)) + dnc_cluster_ctrl_bytes(B, k) - 256);
+    hipError_t rc = hipMemcpyAsync(&e[0], errw, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (rc == hipSuccess) rc = hipMemcpyAsync(&e[1], stk, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (rc == hipSuccess) rc = hipMemsetAsync(stk, 0, sizeof(unsigned), (hipStream_t)stream);      // read and clear
     if (rc == hipSuccess) rc = hipStreamSynchronize((hipStream_t)stream);
     NTK_REQUIRE(rc == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_status: %s", hipGetErrorString(rc));
-    NTK_REQUIRE(e == 0, NTK_ERR_HIP, "ntk_dnc_cluster_status: a cluster hand-off timed out (the launch was aborted; its outputs are invalid)");
+    NTK_REQUIRE(e[0] == 0 && e[1] == 0, NTK_ERR_HIP, "ntk_dnc_cluster_status: a cluster hand-off timed out (%s was aborted; its outputs are invalid)",
+                e[0] ? "the last launch" : "an earlier launch on this workspace");
     return NTK_OK;
 }
 
@@ -852,10 +882,12 @@ extern "C" int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, in
         const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 2, "ntk_dnc_cluster_fwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
-    hipError_t e = hipMemsetAsync(workspace, 0, ctrl, (hipStream_t)stream);     // flags + error word: zero before EVERY launch
+    hipError_t e = hipMemsetAsync(workspace, 0, dnc_cluster_ctrl_zero_bytes(B, k), (hipStream_t)stream);     // flags + error word: zero before EVERY launch
     NTK_REQUIRE(e == hipSuccess, NTK_ERR_HIP, "ntk_dnc_cluster_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
     if (dnc_cluster_is_fix(a.c)) dnc_cluster_fwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     else dnc_cluster_fwd_kernel<false><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
     NTK_CHECK_LAUNCH("ntk_dnc_cluster_fwd");
+    dnc_cluster_latch(a.err, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + ctrl - 256), stream);
+    NTK_CHECK_LAUNCH("ntk_dnc_cluster_fwd (latch)");
     return NTK_OK;
 }

@@ -70,8 +70,8 @@ constexpr __host__ __device__ DncMpBwdLds dnc_mp_bwd_lds(const DncMpCfg& c, cons
     DncMpBwdLds L = {};
     const int N = c.N, RN = c.R * c.N;
     int part = 2 * N;                                                  // the two rank-ordered vectors
-    part = dnc_cluster_max(part, q.RG * c.R * q.NP);                    // link pass: per-row-group column partials
-    part = dnc_cluster_max(part, (CLT / 64) * c.R * c.W);               // memory passes: per-wave column sums
+    part = dnc_cluster_max(part, q.RG * dnc_cluster_max(c.R, 2) * q.NP);            // link pass: per-row-group column partials (R read-weight sums, then 2)
+    part = dnc_cluster_max(part, (CLT / 64) * dnc_cluster_max(c.R, 2) * c.W);       // memory passes: per-wave column sums (R key sums, then erase + write vector)
     part = dnc_cluster_max(part, q.nslZ * q.ldkT);
     part = dnc_cluster_max(part, q.nslH * c.upk);
     int o = 0;

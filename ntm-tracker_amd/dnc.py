@@ -359,6 +359,30 @@ class DNC(object):
                 else:
                     _lib.check(_lib.lib().ntk_dnc_mp_status(_P(ws), nbytes, c[0][0], k, 1 if clear else 0, _lib.stream()), "ntk_dnc_mp_status")
 
+    def guard(self, loss=None, grad=None):
+        """Device-side propagation of an aborted cluster launch (no synchronisation): if a hand-off of any cluster launch
+        since the last check_cluster() timed out, `loss` becomes NaN and `grad` zero (ntk_dnc_cluster_guard)."""
+        for c in (self._cluster, self._cluster_b):
+            if c is not None and c[1] is not None:
+                form, k, ws, nbytes = c[1]
+                _lib.check(_lib.lib().ntk_dnc_cluster_guard(_P(ws), nbytes, 1 if form == "mp" else 0, c[0][0], k,
+                                                            _P(loss) if loss is not None else None,
+                                                            _P(grad) if grad is not None else None,
+                                                            grad.numel() if grad is not None else 0, _lib.stream()),
+                           "ntk_dnc_cluster_guard")
+
+    def _may_overlap(self, B):
+        """May the re-recording forward pass of segment s - 1 run on a side stream WHILE segment s is back-propagated?
+        The cluster kernels are cooperative: every one of their B * k workgroups must be resident (one per CU, their LDS
+        footprint allows no second one) before any hand-off completes.  Two such launches side by side that together want
+        more CUs than the device has can each be dispatched in part and spin on peers that never arrive, until the bounded
+        waits abort both.  So: overlap only when both grids fit the device together."""
+        pf, pb = self._cluster_plan(B), self._cluster_bwd_plan(B)
+        if not pf and not pb:
+            return True                                   # one workgroup per sequence on both sides: nothing waits on a peer
+        need = B * (pf[1] if pf else 1) + B * (pb[1] if pb else 1)
+        return need <= _lib.lib().ntk_cu_count()
+
     def cluster_placement(self):
         """(clusters that ran the same-XCD form of the hand-offs, clusters) of the last forward / BPTT cluster launches;
         a speed diagnostic only (csrc/dnc_cluster.h).  Synchronises."""
@@ -503,7 +527,8 @@ class DNC(object):
         cur = torch.cuda.current_stream(dev)
         if self._rerec_stream is None:
             self._rerec_stream = torch.cuda.Stream(device=dev)
-        side = self._rerec_stream
+        side = self._rerec_stream if self._may_overlap(B) else cur      # cooperative grids that do not fit together: serialise
+        self.last_rerecord_overlapped = side is not cur
         segs = list(zip(reversed(ckpt), reversed(bounds)))
 
         def rerecord(k):
@@ -512,6 +537,9 @@ class DNC(object):
             # allocating on the side stream kept three sets alive and ran out of HBM at config 5); the side stream orders
             # itself after everything enqueued here, which includes the last reader of the memory being reused
             r = self._alloc_records(B, a1 - a0, cap=seg_cap)
+            if side is cur:
+                self._launch_fwd(xp[:, a0:a1].contiguous().view(B * (a1 - a0), 4 * hid), B, a1 - a0, st_k, r)
+                return r, None
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._launch_fwd(xp[:, a0:a1].contiguous().view(B * (a1 - a0), 4 * hid), B, a1 - a0, st_k, r)

@@ -320,6 +320,9 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         logits, _state = self.forward_features(fmap, gts0, record=True)
         loss, pred, dlogits = offset_loss(logits, offsets, self.T)
         self.core.backward_sequence(self._X, dlogits)
+        # a cluster launch that aborted (a hand-off timed out) must not feed the optimiser: loss -> NaN, gradient -> 0, on the
+        # device, without a synchronisation; DNC.check_cluster() raises where the caller next synchronises
+        self.core.guard(loss, self.core.params.grad)
         return loss, pred
 
     def train_step(self, frames, gts0, offsets):

@@ -44,8 +44,42 @@ def _random_state(cfg, B, rng):
     return D.DNCState(reads, acc, D.LSTMState(h, c))
 
 
-@pytest.mark.parametrize("name,Din,O,N,W,R,Wn,hid,clip,S,B,zero", CASES, ids=[c[0] for c in CASES])
-def test_dnc_sequence_matches_oracle(cuda, name, Din, O, N, W, R, Wn, hid, clip, S, B, zero):
+def _with_forms(cases):
+    """Every kernel family a shape can run on gets its own oracle comparison: "seq" = one workgroup per sequence
+    (ntk_dnc_seq_*), "lds" = the LDS-resident cluster form (ntk_dnc_cluster_*), "mp" = the memory-partitioned cluster
+    form (ntk_dnc_mp_*).  Shapes outside the cluster kernels' range (several write heads, memory not a multiple of 64)
+    run once, on whatever the planner picks ("auto" = the seq kernels there)."""
+    out = []
+    for c in cases:
+        N, Wn = c[3], c[6]
+        forms = ("seq", "lds", "mp") if (Wn == 1 and N % 64 == 0) else ("auto",)
+        for f in forms:
+            if f == "lds" and N * N // 8 * 4 + N * (c[4] + 4) * 4 > 150 * 1024:
+                continue                                   # link slice + replicated memory cannot fit 160 KiB of LDS (config 5's shape)
+            out.append(pytest.param(*c, f, id="%s-%s" % (c[0], f)))
+    return out
+
+
+def _select_form(core, form):
+    if form == "seq":
+        core.cluster_k = 0
+    elif form in ("lds", "mp"):
+        core.cluster_form = form
+
+
+def _assert_form(core, form, bwd=False):
+    """The kernel family that RAN is the one the test names (no accidental fallback)."""
+    k = core.last_cluster_bwd_k if bwd else core.last_cluster_k
+    f = core.last_cluster_bwd_form if bwd else core.last_cluster_form
+    if form == "seq":
+        assert k == 1 and f is None, (k, f)
+    elif form in ("lds", "mp"):
+        assert k > 1 and f == form, (form, k, f)
+        core.check_cluster()
+
+
+@pytest.mark.parametrize("name,Din,O,N,W,R,Wn,hid,clip,S,B,zero,form", _with_forms(CASES))
+def test_dnc_sequence_matches_oracle(cuda, name, Din, O, N, W, R, Wn, hid, clip, S, B, zero, form):
     from ntmtrack.dnc import DNC
     cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=Wn, hidden_size=hid, clip_value=clip)
     rng = np.random.default_rng(5)
@@ -73,8 +107,10 @@ def test_dnc_sequence_matches_oracle(cuda, name, Din, O, N, W, R, Wn, hid, clip,
         gst = G.DNCState(t(st0.access_output), G.AccessState(t(a0.memory), t(a0.read_weights), t(a0.write_weights),
                          G.TemporalLinkageState(t(a0.linkage.link), t(a0.linkage.precedence_weights)), t(a0.usage)),
                          G.LSTMState(t(st0.controller_state.hidden), t(st0.controller_state.cell)))
+    _select_form(core, form)
     out, st = core.run_sequence(torch.from_numpy(x).to(cuda), gst)
     torch.cuda.synchronize()
+    _assert_form(core, form)
     tol = dict(atol=5e-5, rtol=0)
     np.testing.assert_allclose(out.cpu().numpy(), ys, **tol)
     acc = st.access_state
@@ -163,10 +199,14 @@ BWD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("name,Din,O,N,W,R,Wn,hid,clip,S,B,zero", BWD_CASES, ids=[c[0] for c in BWD_CASES])
-def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, Wn, hid, clip, S, B, zero):
-    """d(sum(y * G)) / d(params) through S recorded steps vs torch-autograd on the float64 restatement.
-    Inputs are chosen without near-tied usages (see _random_state) so the allocation sort is well conditioned."""
+@pytest.mark.parametrize("name,Din,O,N,W,R,Wn,hid,clip,S,B,zero,form", _with_forms(BWD_CASES))
+def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, Wn, hid, clip, S, B, zero, form):
+    """d(sum(y * G)) / d(params) through S recorded steps vs torch-autograd on the float64 restatement, on every kernel
+    family the shape can run on (the family that ran is asserted).  Inputs are chosen without near-tied usages (see
+    _random_state) so the allocation sort is well conditioned.
+    Bound per tensor, relative to the tensor's largest gradient: 1e-4 -- or, for the tensors whose gradient is a sum with
+    heavy cancellation (keys / strengths: the float32 evaluation of the SAME restatement is itself further than that from
+    float64), no further from float64 than 3x what that float32 evaluation is."""
     from oracle import dnc_oracle_torch as DT
     from ntmtrack import dnc as G
     cfg = D.DNCConfig(Din, O, memory_size=N, word_size=W, num_reads=R, num_writes=Wn, hidden_size=hid, clip_value=clip)
@@ -192,9 +232,21 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, W
                           DT.LSTMState(t64(st0.controller_state.hidden), t64(st0.controller_state.cell)))
     ys, _ = DT.run_model(cfg, pt, t64(x), ost)
     (ys * t64(Gy)).sum().backward()
+    # the same restatement evaluated in float32: how far a float32 evaluation of these sums is from float64
+    t32 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float32)
+    pt32 = {k: t32(v).requires_grad_(True) for k, v in p.items()}
+    ost32 = None
+    if st0 is not None:
+        a0 = st0.access_state
+        ost32 = DT.DNCState(t32(st0.access_output), DT.AccessState(t32(a0.memory), t32(a0.read_weights), t32(a0.write_weights),
+                            DT.TemporalLinkageState(t32(a0.linkage.link), t32(a0.linkage.precedence_weights)), t32(a0.usage)),
+                            DT.LSTMState(t32(st0.controller_state.hidden), t32(st0.controller_state.cell)))
+    ys32, _ = DT.run_model(cfg, pt32, t32(x), ost32)
+    (ys32 * t32(Gy)).sum().backward()
 
     core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": Wn}, {"hidden_size": hid}, O, clip, device=cuda)
     core.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    _select_form(core, form)
     gst = None
     if st0 is not None:
         t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(cuda)
@@ -206,14 +258,21 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, W
     np.testing.assert_allclose(out.cpu().numpy(), ys.detach().numpy(), atol=5e-5)
     assert {k: tuple(v.shape) for k, v in core.state_dict().items()} == {k: v.shape for k, v in p.items()}
     dout = torch.from_numpy(np.ascontiguousarray(np.transpose(Gy, (1, 0, 2)))).to(cuda)      # [B,S,O]
+    _assert_form(core, form)
     grads = core.backward_sequence(core.last_X, dout)
     torch.cuda.synchronize()
-    worst = {}
+    _assert_form(core, form, bwd=True)
+    worst, bad = {}, {}
     for k in sorted(p):
         ref = pt[k].grad.numpy()
         got = grads[k].cpu().numpy()
-        worst[k] = float(np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) + 1e-30))
-    bad = {k: v for k, v in worst.items() if v > 3e-3}
+        scale = np.max(np.abs(ref)) + 1e-30
+        err = float(np.max(np.abs(got - ref)) / scale)
+        err32 = float(np.max(np.abs(pt32[k].grad.double().numpy() - ref)) / scale)
+        worst[k] = (err, err32)
+        if err > max(1e-4, 3 * err32):
+            bad[k] = (err, err32)
+    print("%s/%s relative gradient error (HIP, float32 oracle) vs float64: %s" % (name, form, {k: ("%.1e" % a, "%.1e" % b) for k, (a, b) in worst.items()}))
     assert not bad, bad
 
 
@@ -356,8 +415,9 @@ CLUSTER_CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", ["lds", "mp"])
 @pytest.mark.parametrize("name,N,W,R,hid,S,B,ks", CLUSTER_CASES, ids=[c[0] for c in CLUSTER_CASES])
-def test_dnc_cluster_forward_equals_single_workgroup_kernel(cuda, name, N, W, R, hid, S, B, ks):
+def test_dnc_cluster_forward_equals_single_workgroup_kernel(cuda, name, N, W, R, hid, S, B, ks, form):
     """The cluster form (k workgroups per sequence, LDS-resident link rows, two mailbox exchanges per step) against the
     one-workgroup-per-sequence kernel (itself checked against the oracle above): outputs, final state and EVERY BPTT
     record, from a random non-degenerate state, for several cluster sizes."""
@@ -383,9 +443,11 @@ def test_dnc_cluster_forward_equals_single_workgroup_kernel(cuda, name, N, W, R,
         core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, 20.0, device=cuda)
         core.load_state_dict({kk: torch.from_numpy(v) for kk, v in p.items()})
         core.cluster_k = k
+        core.cluster_form = form if k else None
         out, st = core.run_sequence(x, gst, record=True)
         core.check_cluster()
         torch.cuda.synchronize()
+        assert k == 0 or core.last_cluster_k == 1 or core.last_cluster_form == form
         return out, st, core.last_record, core.last_cluster_k
 
     ref_out, ref_st, ref_rec, used = run(0)
@@ -438,8 +500,9 @@ def test_dnc_cluster_forward_full_length_is_deterministic(cuda):
     assert torch.equal(o5[:, 0], o1[:, 5])
 
 
+@pytest.mark.parametrize("form", ["lds", "mp"])
 @pytest.mark.parametrize("name,N,W,R,hid,S,B,ks", CLUSTER_CASES, ids=[c[0] for c in CLUSTER_CASES])
-def test_dnc_cluster_bptt_equals_single_workgroup_kernel(cuda, name, N, W, R, hid, S, B, ks):
+def test_dnc_cluster_bptt_equals_single_workgroup_kernel(cuda, name, N, W, R, hid, S, B, ks, form):
     """Cluster BPTT (d(link) rows LDS resident and split k ways, d(memory) in registers, two exchanges per step) against
     the one-workgroup-per-sequence BPTT kernel (itself checked against torch autograd above) on the same recorded
     sequence: every gradient tensor to 1e-4 of its largest entry, bitwise identical across two runs (no float
@@ -467,11 +530,13 @@ def test_dnc_cluster_bptt_equals_single_workgroup_kernel(cuda, name, N, W, R, hi
         core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, 20.0, device=cuda)
         core.load_state_dict({kk: torch.from_numpy(v) for kk, v in p.items()})
         core.cluster_k = k
+        core.cluster_form = form if k else None
         core.bptt_segment = segment
         core.run_sequence(x, gst, record=True)
         grads = core.backward_sequence(core.last_X, dout)
         core.check_cluster()
         torch.cuda.synchronize()
+        assert k == 0 or core.last_cluster_bwd_k == 1 or core.last_cluster_bwd_form == form
         return {kk: v.clone() for kk, v in grads.items()}, core.last_cluster_bwd_k
 
     ref, used = run(0)
@@ -495,3 +560,68 @@ def test_dnc_cluster_bptt_equals_single_workgroup_kernel(cuda, name, N, W, R, hi
             err = float(np.max(np.abs(a_ - b_)) / (np.max(np.abs(b_)) + 1e-30))
             assert err < 2e-5, "segmented %s k=%d: %.3e" % (kk, k, err)
     assert tried >= 1
+
+
+@pytest.mark.parametrize("form", ["lds", "mp"])
+def test_dnc_segmented_bptt_does_not_overlap_two_cooperative_grids(cuda, form):
+    """Segmented BPTT re-records segment s - 1 while segment s is back-propagated -- on a side stream only when both
+    grids fit the device together.  The cluster kernels are cooperative (every workgroup of a launch must be resident
+    before any hand-off completes): at B 32 x k 8 the re-recording forward and the backward each want all 256 CUs, side
+    by side each could be half-dispatched and spin until the bounded waits abort both.  Here: the passes are serialised
+    (last_rerecord_overlapped False), no hand-off times out, and the gradients equal the unsegmented run's."""
+    from ntmtrack import dnc as G
+    N, W, R, hid, O, Din, S, B, k = 64, 16, 2, 32, 2, 20, 12, 32, 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((S, B, Din), generator=g).to(cuda)
+    dout = torch.randn((B, S, O), generator=g).to(cuda)
+    res = {}
+    for seg in (None, S // 3):
+        core = G.DNC({"memory_size": N, "word_size": W, "num_reads": R, "num_writes": 1}, {"hidden_size": hid}, O, 20.0,
+                     input_dim=Din, device=cuda, seed=6)
+        core.cluster_k, core.cluster_form, core.bptt_segment = k, form, seg
+        out, _ = core.run_sequence(x, None, record=True)
+        grads = core.backward_sequence(core.last_X, dout)
+        core.check_cluster()
+        torch.cuda.synchronize()
+        assert core.last_cluster_k == k and core.last_cluster_bwd_k == k and core.last_cluster_form == form
+        if seg is not None:
+            assert core.last_segments is not None and core.last_rerecord_overlapped is False
+        res[seg] = (out.clone(), {kk: v.clone() for kk, v in grads.items()})
+    assert torch.equal(res[None][0], res[S // 3][0])
+    for kk, gref in res[None][1].items():
+        err = float((res[S // 3][1][kk] - gref).abs().max() / (gref.abs().max() + 1e-30))
+        assert err <= 2e-5, (kk, err)
+
+
+def test_dnc_cluster_abort_reaches_the_loss_without_a_sync(cuda):
+    """An aborted cluster launch must not feed the optimiser silently: with the workspace's sticky error word set (what a
+    timed-out hand-off does), DNC.guard turns the loss into NaN and the gradient into zeros on the device, and
+    check_cluster raises -- and clears the word."""
+    from ntmtrack import dnc as G
+    from ntmtrack._lib import NtkError
+    for form in ("lds", "mp"):
+        core = G.DNC({"memory_size": 64, "word_size": 16, "num_reads": 2, "num_writes": 1}, {"hidden_size": 32}, 2, 20.0,
+                     input_dim=20, device=cuda, seed=6)
+        core.cluster_k, core.cluster_form = 4, form
+        x = torch.randn((5, 2, 20), generator=torch.Generator().manual_seed(1)).to(cuda)
+        core.run_sequence(x, None, record=True)
+        core.backward_sequence(core.last_X, torch.ones((2, 5, 2), device=cuda))
+        loss, grad = torch.ones(1, device=cuda), core.params.grad
+        core.guard(loss, grad)
+        torch.cuda.synchronize()
+        assert float(loss) == 1.0 and float(grad.abs().max()) > 0          # clean run: untouched
+        plan = core._cluster_plan(2)
+        ws, nbytes = plan[2], plan[3]
+        # plant what mp_wait / the latch kernel write on a timeout: the sticky word of the forward workspace
+        import ctypes
+        from ntmtrack import _lib
+        off = (nbytes - 256) if form == "mp" else None
+        if off is None:                                                     # lds form: last line of the control block
+            off = ((2 * 3 * 4 + 1) * 4 + 255) // 256 * 256
+        ws.view(torch.int32)[off // 4] = 1
+        core.guard(loss, grad)
+        torch.cuda.synchronize()
+        assert torch.isnan(loss).all() and float(grad.abs().max()) == 0.0
+        with pytest.raises(NtkError):
+            core.check_cluster()
+        core.check_cluster()                                                # the word was cleared
