@@ -142,10 +142,17 @@ class _TwoStreamPipeline(object):
             self._proj_done = torch.cuda.Event()
             self._proj_done.record(torch.cuda.current_stream(self.device))
 
+    #: True: the trunk pass and the core pass share ONE stream (strictly alternating).  Set by trackers whose core runs as a
+    #: cooperative cluster launch over (nearly) every CU: such a launch cannot start until all its workgroups are resident,
+    #: so a trunk pass beside it does not overlap anything -- its short workgroups keep taking the CUs the cluster is waiting
+    #: for while the already resident cluster workgroups spin (measured at BASELINE configs[4]: 1 110 ms per step with two
+    #: streams, trunk 136 ms + core 703 ms alone).
+    serial_trunk = False
+
     def _streams(self):
         if self._s_vgg is None:
-            self._s_vgg = torch.cuda.Stream(device=self.device)
             self._s_ntm = torch.cuda.Stream(device=self.device, priority=-1)
+            self._s_vgg = self._s_ntm if self.serial_trunk else torch.cuda.Stream(device=self.device)
         return self._s_vgg, self._s_ntm
 
     def submit_features(self, frames):
@@ -296,6 +303,11 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         # _with_dnc.py:615-620: clip_by_global_norm(50), RMSPropOptimizer(lr, epsilon=1e-10) -> decay 0.9, momentum 0
         self.opt = RMSPropClip(self.core.params, learning_rate, 0.9, 0.0, optimizer_epsilon, max_gradient_norm)
         self.add_pipeline()
+        if os.environ.get("NTK_DNC_SERIAL_TRUNK"):
+            self.serial_trunk = os.environ["NTK_DNC_SERIAL_TRUNK"] != "0"
+        else:
+            plan = self.core._cluster_plan(self.B)
+            self.serial_trunk = bool(plan) and 2 * self.B * plan[1] > _lib.lib().ntk_cu_count()
 
     def _flat_grad(self):
         return self.core.params.grad
