@@ -140,16 +140,23 @@ def cpu_baseline(ws, n_vgg_frames=8, T=20, model="ntm", dnc_shape=(256, 64)):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))      # the box's CPU share for one GPU is 16 cores
+    cores = max(1, cores)               # every core this process may run on ("all cores")
     fps, t_vgg, t_ntm = _cpu_sample(ws, cores, n_vgg_frames, T, O, OT, model, dnc_shape)
+    share = None
+    if cores > 16:                      # also the box's CPU share for ONE GPU (16 cores): what a one-GPU-per-process job would get
+        fps16, t_vgg16, t_ntm16 = _cpu_sample(ws, 16, n_vgg_frames, T, O, OT, model, dnc_shape)
+        share = {"value": round(fps16, 3), "unit": "frames/sec", "cores": 16, "vgg_s_per_frame": round(t_vgg16, 3),
+                 "ntm_s_per_sequence": round(t_ntm16, 2)}
     fps1, t_vgg1, t_ntm1 = _cpu_sample(ws, 1, 2, T, O, OT, model, dnc_shape)
-    torch.set_num_threads(cores)
+    torch.set_num_threads(min(cores, 16))
     out = {"value": round(fps, 3), "unit": "frames/sec", "cores": cores, "kind": "port",
            "sample": "VGG conv1_1..conv4_3 on %d frames (torch-CPU conv2d, %.3f s/frame) + %s fwd+BPTT of 1 "
                      "sequence x %d frames (torch-CPU autograd restatement, %.2f s); frames/s of one sequence"
                      % (n_vgg_frames, t_vgg, "NTM" if model == "ntm" else "DNC(%dx%d)" % dnc_shape, T, t_ntm),
            "single_thread": {"value": round(fps1, 3), "unit": "frames/sec", "vgg_s_per_frame": round(t_vgg1, 3),
                              "ntm_s_per_sequence": round(t_ntm1, 2)}}
+    if share is not None:
+        out["one_gpu_cpu_share"] = share
     out.update(host_cpu_info())
     return out
 
@@ -158,6 +165,10 @@ def cpu_baseline(ws, n_vgg_frames=8, T=20, model="ntm", dnc_shape=(256, 64)):
 DNC_FWD_TRAFFIC_BYTES_B32_S1300 = 4.56e9        # inference-mode forward (2 x FETCH_SIZE + WRITE_SIZE)
 DNC_BWD_TRAFFIC_BYTES_B32_S1300 = 2.123e10
 NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.950e9 + 0.162e9   # profiles/r02_ntm_seq_hbm_traffic_pmc.csv
+# HBM-side bytes per sequence-step of the memory-partitioned DNC cluster kernels at configs[4]'s shape (512 x 128, B 64):
+# profiles/r03_dnc_mp_hbm_traffic_pmc.csv (None until measured)
+DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = None
+DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP = None
 
 
 def _median_ms(fn, n=3):
@@ -203,23 +214,32 @@ def memory_step_probe(trk, model, gts0, offs, B, T):
         _loss, _pred, dlogits = T_.offset_loss(logits, offs, T)
         ms_b = _median_ms(lambda: c.backward_sequence(trk._X, dlogits))
         c.check_cluster()
-        k = getattr(c, "last_cluster_k", 1)
-        kern = "dnc_cluster_fwd_kernel (k = %d workgroups per sequence)" % k if k > 1 else "dnc_seq_fwd_kernel"
-        kern_b = ("dnc_cluster_bwd_kernel (k = %d)" % getattr(c, "last_cluster_bwd_k", 1) if getattr(c, "last_cluster_bwd_k", 1) > 1
-                  else "dnc_seq_bwd_kernel") + " (+ 4 weight-gradient GEMMs)"
-        is_c3 = (c.N, c.W, c.R) == (256, 64, 4) and k > 1
-        traffic = DNC_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else None
-        traffic_b = DNC_BWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else None
-        note = ("serialise + input projection + persistent cluster kernel: link rows and memory LDS resident, two mailbox hand-offs per step"
-                if k > 1 else "serialise + input projection + persistent sequence kernel, one workgroup per sequence; link and memory L2 resident")
-        tnote = "PMC, profiles/r02_dnc_cluster_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE)"
+        k, kb = getattr(c, "last_cluster_k", 1), getattr(c, "last_cluster_bwd_k", 1)
+        form, form_b = getattr(c, "last_cluster_form", None), getattr(c, "last_cluster_bwd_form", None)
+        fam = {"lds": "dnc_cluster_%s_kernel", "mp": "dnc_mp_%s_kernel"}
+        kern = (fam[form] % "fwd" + " (k = %d workgroups per sequence)" % k) if k > 1 else "dnc_seq_fwd_kernel"
+        kern_b = ((fam[form_b] % "bwd" + " (k = %d)" % kb) if kb > 1 else "dnc_seq_bwd_kernel") + " (+ 4 weight-gradient GEMMs)"
+        if getattr(c, "last_segments", None):
+            kern_b += "; %d BPTT segments: this time includes re-recording all but the last with the forward kernel" % len(c.last_segments[1])
+        is_c3 = (c.N, c.W, c.R) == (256, 64, 4) and form == "lds"
+        is_c5 = (c.N, c.W, c.R) == (512, 128, 4) and form == "mp"
+        traffic = DNC_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else (
+            DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if (is_c5 and DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP) else None)
+        traffic_b = DNC_BWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else (
+            DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if (is_c5 and DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP) else None)
+        note = {"lds": "serialise + input projection + persistent cluster kernel: link rows and memory LDS resident, two mailbox hand-offs per step",
+                "mp": "serialise + input projection + persistent memory-partitioned cluster kernel: the link streams through HBM once per step "
+                      "(N/k rows per workgroup), memory rows LDS resident, four mailbox hand-offs per step; HBM-bound link pass",
+                None: "serialise + input projection + persistent sequence kernel, one workgroup per sequence; link and memory L2 resident"}[form]
+        tnote = ("PMC, profiles/r03_dnc_mp_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE), inference-mode forward / BPTT kernel alone" if is_c5
+                 else "PMC, profiles/r02_dnc_cluster_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE)")
         if k > 1:
             pl = c.cluster_placement()
             note += "; clusters on one XCD handing off through that XCD's L2 (forward, BPTT launch): " + ", ".join("%d of %d" % x for x in pl)
 
     def entry(kernel, t_ms, tr):
         gbps = per_step * B * S / (t_ms * 1e-3) / 1e9
-        return {"kernel": kernel, "bound": "hbm (nominal); dependency-chain latency (actual)",
+        return {"kernel": kernel, "bound": "hbm" if (model == "dnc" and getattr(trk.core, "last_cluster_form", None) == "mp") else "hbm (nominal); dependency-chain latency (actual)",
                 "algorithmic_bytes_per_sequence_step": per_step, "sequences": B, "steps": S,
                 "ms": round(t_ms, 3), "us_per_step": round(t_ms * 1e3 / S, 3),
                 "achieved": round(gbps, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 5),

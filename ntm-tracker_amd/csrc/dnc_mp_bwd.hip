@@ -17,6 +17,22 @@
 #include "dnc_mp.h"
 #include <stdlib.h>
 
+// Diagnostic build only (-DNTK_CL_PROF): workgroup 0's thread 0 adds s_memtime deltas per phase to g_mpb_prof (global atomics: no
+// registers held across the step); ntk_dnc_mp_bwd_prof copies them out.  The stamps serialise the phases: read SHARES.
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_mpb_prof[32];
+#define MP_STAMP(i)                                                                   \
+    do {                                                                              \
+        if (blockIdx.x == 0 && tid == 0) {                                            \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+            __hip_atomic_fetch_add(&g_mpb_prof[i], now_ - prof_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            prof_last = now_;                                                         \
+        }                                                                             \
+    } while (0)
+#else
+#define MP_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int MPQ = 8;        // memory rows per lane group (own rows <= 8 * 512 / LPR)
@@ -206,6 +222,10 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         plain = __builtin_amdgcn_readfirstlane(same) != 0;
     }
 
+#ifdef NTK_CL_PROF
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && tid0 == 0) for (int i = 0; i < 32; ++i) g_mpb_prof[i] = 0;
+#endif
     for (int t = S - 1; t >= 0; --t) {
         ArgsK ak = ak0;
         asm volatile("" : "+s"(ak));
@@ -245,6 +265,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         float* slot3 = mb3 + ((size_t)par * k + g) * sl3;
         float* slot4 = mb4 + ((size_t)par * k + g) * sl4;
 
+        MP_STAMP(0);       // loop top
         // ------------------------------------------------------------ this step's records -> LDS
         float pf_cr[8], pf_fv[8], pf_bv[8];                   // B3: wave i < R, slots lane + 64 j
         {
@@ -318,6 +339,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             cl_store(slot1 + 2 * R * NR + n, __int_as_float(cnt), plain);
         }
         __syncthreads();
+        MP_STAMP(1);       // records -> LDS, B1, key norms, rank partial
         // ------------------------------------------------------------ B2: pass 1 over M_t (registers): d(rw) through the reads, read-key scores
         float nmr[MPQ];                                       // |M_t[n]| of the rows of this group
         {
@@ -354,6 +376,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 }
             }
         }
+        MP_STAMP(2);       // B2
         cl_publish(fl1 + g, epoch, tid, plain);
         // B15's records (gates, cells of the own units) of this step: requested here, used after the link pass
         f32x4 pf_gates = {0.f, 0.f, 0.f, 0.f};
@@ -365,7 +388,9 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             pf_c = a.rec_c[bt * hid + u];
             pf_cprev = p_cprev[u];
         }
+        MP_STAMP(3);       // publish 1 + gate record requests
         if (!mp_wait(fl1, epoch, k, a.err, a.sticky, sAbort, tid)) return;
+        MP_STAMP(4);       // wait 1
         {   // consume hand-off 1: G and the read-key scores of every slot; ranks
             const float* base = mb1 + (size_t)par * k * sl1;
             for (int idx = tid; idx < RN; idx += CT) {
@@ -385,6 +410,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
         }
         __syncthreads();
+        MP_STAMP(5);       // consume 1
         // ------------------------------------------------------------ B3: read-weight mix, read-content softmax (wave i = head i)
         if (wave < R) {
             const int i = wave;
@@ -422,6 +448,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
         }
         __syncthreads();
+        MP_STAMP(6);       // B3
         // ------------------------------------------------------------ B4: pass 2 over M_t: d(M_t) (registers) and d(read keys) of the own rows
         {
             f32x4 accK[4];
@@ -492,6 +519,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 cl_store(slot2 + Q.oNk + tid, s, plain);
             }
         }
+        MP_STAMP(7);       // B4 + its column sums
         // M_t is dead from here: its registers take the own memory rows of step t-1 (requested now, first used in B7)
         {
             const float* Mpg = (t > 0) ? a.rec_M + ((bt - 1) * N + row0) * W : a.mem0 + ((size_t)b * N + row0) * W;
@@ -505,6 +533,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
         }
         __syncthreads();                                      // sPart free again
+        MP_STAMP(8);       // M_{t-1} requests
         // ------------------------------------------------------------ B5: link pass over the own rows (d(link), L_t, L_{t-1}: HBM streams)
         {
             const int NH = C.NH, RG = Q.RG, NP = Q.NP;
@@ -579,6 +608,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                     }
                 }
             }
+            MP_STAMP(9);       // B5 link rows
             // column partials: fixed-order sums over the row groups.  round 1: the read-weight products
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -612,6 +642,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
             __syncthreads();
         }
+        MP_STAMP(10);      // B5 column reductions
         // ------------------------------------------------------------ B7: write backward over (dM, M_{t-1}) of the own rows; write-key scores
         float nmw[MPQ];
         {
@@ -667,8 +698,10 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 cl_store(slot2 + (which ? Q.oV : Q.oE) + w, s, plain);
             }
         }
+        MP_STAMP(11);      // B7
         cl_publish(fl2 + g, epoch, tid, plain);
         if (!mp_wait(fl2, epoch, k, a.err, a.sticky, sAbort, tid)) return;
+        MP_STAMP(12);      // publish 2 + wait 2
         {   // consume hand-off 2
             const float* base = mb2 + (size_t)par * k * sl2;
             for (int idx = tid; idx < RN; idx += CT) {
@@ -721,6 +754,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 }
             }
         }
+        MP_STAMP(13);      // consume 2
         // ------------------------------------------------------------ B6: precedence (wave 0 computes the two scalars)
         if (wave == 0) {
             float sw = 0.f, t1 = 0.f;
@@ -804,6 +838,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             const float bw = sI[C.oBw];
             if (lane == 0) sDX[C.oBw] = dbeta * (1.0f - expf(-bw));
         }
+        MP_STAMP(14);      // B6, B8, B9
         // ------------------------------------------------------------ B10b: content part of d(M_{t-1}) (registers), d(write key) of the own rows
         {
             f32x4 accKw = {0.f, 0.f, 0.f, 0.f};
@@ -862,6 +897,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
         }
         __syncthreads();
+        MP_STAMP(15);      // B10b, B11
         {   // publish hand-off 3: partial d(write key) column sums + partial d|kw|
             for (int w = tid; w < W; w += CT) {
                 float s = 0.f;
@@ -887,6 +923,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         }
         for (int i = tid; i < RN; i += CT) sgRW[i] = sDRWp[i];                  // carried d(read weights_{t-1})
         for (int n = tid; n < N; n += CT) sgP[n] = sDPp[n];                     // carried d(precedence_{t-1})
+        MP_STAMP(16);      // publish 3, free gates, carried vectors
         if (!mp_wait(fl3, epoch, k, a.err, a.sticky, sAbort, tid)) return;
         {
             const float* base = mb3 + (size_t)par * k * sl3;
@@ -903,6 +940,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         __syncthreads();
         if (g == 0) for (int c = tid; c < IP; c += CT) a.dxi[bt * IP + c] = sDX[c];
 
+        MP_STAMP(17);      // wait 3 + consume + dxi out
         // ------------------------------------------------------------ B14: d(clipped h) of the own units += d(interface) . Wi^T
         if (tid < Q.nslH * upk) {
             const int sl = cl_div(tid, C.mg_upk), j = tid - sl * upk;
@@ -941,6 +979,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             reinterpret_cast<f32x4*>(a.dgates)[bt * hid + u] = dg;
         }
         __syncthreads();
+        MP_STAMP(18);      // B14, B15
         // ------------------------------------------------------------ B16: partial d[reads_prev ; h_prev] over the own gate columns
         {
             const int kg4 = Q.kg4, nrow = 4 * nU;
@@ -959,6 +998,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
             cl_publish(fl4 + g, epoch, tid, plain);
         }
+        MP_STAMP(19);      // B16 + publish 4
         if (!mp_wait(fl4, epoch, k, a.err, a.sticky, sAbort, tid)) return;
         {
             const float* base = mb4 + (size_t)par * k * sl4;
@@ -972,8 +1012,12 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 sGZ[kk] = s;
             }
         }
+        MP_STAMP(20);      // wait 4 + consume
         __syncthreads();
     }
+#ifdef NTK_CL_PROF
+    (void)prof_last;
+#endif
 
     // ---- carried gradients out (segmented BPTT); d(memory) scratch updated in place (d(link) already is)
     {
@@ -1003,6 +1047,12 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
+#ifdef NTK_CL_PROF
+extern "C" int ntk_dnc_mp_bwd_prof(unsigned long long* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mpb_prof), 32 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#endif
+
 static int dnc_mp_bwd_pick(int B, int N, int W, int R, int Wn, int hid, int O, int k_req, DncMpCfg& c, DncMpBwdGeo& q, size_t* lds_bytes) {
     if (Wn != 1 || R < 1 || R > 4 || N < 64 || (N % 64) != 0 || N > CT || W < 4 || (W % 4) != 0 || W > 256 || hid < 4 ||
         (hid % 4) != 0 || hid > 1024 || O < 1 || O > 16 || B < 1)

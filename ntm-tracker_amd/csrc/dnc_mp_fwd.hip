@@ -15,6 +15,22 @@
 #include "dnc_mp.h"
 #include <vector>
 
+// Diagnostic build only (-DNTK_CL_PROF): workgroup 0's thread 0 adds s_memtime deltas per phase to g_mpf_prof (global atomics: no
+// registers held across the step); ntk_dnc_mp_fwd_prof copies them out.  The stamps serialise the phases: read SHARES.
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_mpf_prof[24];
+#define MP_STAMP(i)                                                                   \
+    do {                                                                              \
+        if (blockIdx.x == 0 && tid == 0) {                                            \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+            __hip_atomic_fetch_add(&g_mpf_prof[i], now_ - prof_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            prof_last = now_;                                                         \
+        }                                                                             \
+    } while (0)
+#else
+#define MP_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 struct DncMpFwdLds {
@@ -149,6 +165,10 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
         plain = __builtin_amdgcn_readfirstlane(same) != 0;
     }
 
+#ifdef NTK_CL_PROF
+    unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && tid0 == 0) for (int i = 0; i < 24; ++i) g_mpf_prof[i] = 0;
+#endif
     for (int t = 0; t < S; ++t) {
         ArgsK ak = ak0;
         asm volatile("" : "+s"(ak));
@@ -180,6 +200,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
         const unsigned epoch = (unsigned)t + 1u;
         const int par = t & 1;
 
+        MP_STAMP(0);       // loop top / previous step's tail
         // ------------------------------------------------------------ P1: LSTM gates of the own hidden units
         f32x4 xg = {0.f, 0.f, 0.f, 0.f};
         if (tid < nU) xg = reinterpret_cast<const f32x4*>(a.xproj)[bt * hid + u0 + tid] + Wr4[(size_t)K * hid + u0 + tid];
@@ -210,6 +231,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             }
         }
         __syncthreads();
+        MP_STAMP(1);       // P1 gates + LSTM
         // ------------------------------------------------------------ P2: interface partial sums over the own units
         if (tid < nslI * icg) {
             const int us = cl_div(tid, C.mg_icg), cg = tid - us * icg;
@@ -221,6 +243,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             sPart4[us * icg + cg] = acc;
         }
         __syncthreads();
+        MP_STAMP(2);       // P2 interface partial
         {   // publish hand-off 0: [h of the own units | interface partial]
             float* slot = mb0 + ((size_t)par * k + g) * sl0;
             if (tid < nU) cl_store(slot + tid, sZ[RWd + u0 + tid], plain);
@@ -247,7 +270,9 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
                 if (rec) a.rec_ypre[(bt - 1) * C.O + o] = pre;
             }
         }
+        MP_STAMP(3);       // publish 0 + deferred output
         if (!mp_wait(fl0, epoch, k, a.err, a.sticky, sAbort, tid)) return;
+        MP_STAMP(4);       // wait 0
         {   // consume hand-off 0: full h, activated interface (+ aligned copies of the keys)
             const float* base = mb0 + (size_t)par * k * sl0;
             for (int u = tid; u < hid; u += CT) {
@@ -287,6 +312,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
                 a.rec_ifc[bt * IP + c] = v;
             }
         }
+        MP_STAMP(5);       // consume 0 + records
         // key norms: wave i < 1 + R  ->  sSC[8 + i] = sqrt(|key_i|^2 + eps)
         if (wave < 1 + R) {
             float ss = 0.f;
@@ -326,6 +352,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             const float s = e0 + e1 + e2;
             rm[0] = e0 / s; rm[1] = e1 / s; rm[2] = e2 / s;
         }
+        MP_STAMP(6);       // key norms, P3 usage
         float* slotA = mbA + ((size_t)par * k + g) * slA;                          // [scores NR | rank partial counts N]
         // ------------------------------------------------------------ P4: write content scores of the own rows on M_{t-1}
         {
@@ -355,8 +382,10 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             }
             cl_store(slotA + NR + n, __int_as_float(cnt), plain);
         }
+        MP_STAMP(7);       // P4 write scores + P5a rank partial
         cl_publish(flA + g, epoch, tid, plain);
         if (!mp_wait(flA, epoch, k, a.err, a.sticky, sAbort, tid)) return;
+        MP_STAMP(8);       // publish A + wait A
         // ------------------------------------------------------------ P5b: ranks; usages scattered into rank order; write-content scores
         {
             const float* base = mbA + (size_t)par * k * slA;
@@ -403,6 +432,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             }
         }
         __syncthreads();
+        MP_STAMP(9);       // P5b-d allocation, write weights
         float* slotB = mbB + ((size_t)par * k + g) * slB;              // [fwd R x NR | read scores R x NR | bwd partial R x N]
         if (wave == CW - 1) {                                          // sum of the write weights (precedence update)
             float s = 0.f;
@@ -447,6 +477,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
                 }
             }
         }
+        MP_STAMP(10);      // P6 memory write + read scores
         // ------------------------------------------------------------ P7: link pass over the own rows (HBM stream)
         {
             const float* Lsrc = (rec && t > 0) ? a.rec_L + ((bt - 1) * N + row0) * N : a.link + ((size_t)b * N + row0) * N;
@@ -520,6 +551,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
                     }
                 }
             }
+            MP_STAMP(11);      // P7 link rows
             // backward-read partials: fixed-order reduction over the waves, one 256-column half at a time
             for (int h = 0; h < NH; ++h) {
                 if (h > 0) __syncthreads();
@@ -538,8 +570,10 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
                 }
             }
         }
+        MP_STAMP(12);      // P7 column reduction
         cl_publish(flB + g, epoch, tid, plain);
         if (!mp_wait(flB, epoch, k, a.err, a.sticky, sAbort, tid)) return;
+        MP_STAMP(13);      // publish B + wait B
         // ------------------------------------------------------------ P8: read weights, precedence, reads
         {
             const float* base = mbB + (size_t)par * k * slB;
@@ -590,6 +624,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             }
         }
         __syncthreads();
+        MP_STAMP(14);      // P8 read weights
         // reads = rw x M_t over the own rows: thread = (head, float4 of the word) x row slice, slices summed in a fixed order
         if (tid < C.nslR * C.RW4) {
             const int sl = cl_div(tid, C.mg_RW4), o4 = tid - sl * C.RW4;
@@ -611,6 +646,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             }
             cl_publish(flC + g, epoch, tid, plain);
         }
+        MP_STAMP(15);      // reads partial + publish C
         if (!mp_wait(flC, epoch, k, a.err, a.sticky, sAbort, tid)) return;
         {
             const float* base = mbC + (size_t)par * k * slC;
@@ -626,8 +662,12 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
             }
             if (rec && g == 0 && tid < C.ldy - C.Ky) a.rec_yin[bt * C.ldy + C.Ky + tid] = (tid == 0) ? 1.f : 0.f;
         }
+        MP_STAMP(16);      // wait C
         __syncthreads();
     }
+#ifdef NTK_CL_PROF
+    (void)prof_last;
+#endif
 
     // ---- store state: own rows of the memory, own units of the cell; the replicated vectors by workgroup 0
     {
@@ -695,6 +735,12 @@ static int dnc_mp_pick(int B, int N, int W, int R, int Wn, int hid, int O, int k
     }
     return 0;
 }
+
+#ifdef NTK_CL_PROF
+extern "C" int ntk_dnc_mp_fwd_prof(unsigned long long* out24) {
+    return hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_mpf_prof), 24 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#endif
 
 extern "C" int ntk_dnc_mp_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes) {
     DncMpCfg c;

@@ -158,3 +158,44 @@ def test_config3_fullsize_dnc_training_step_properties(cuda):
     np.testing.assert_allclose(float(loss_f.cpu()), 2 * float(loss_h.cpu()), rtol=1e-5)
     gh, gf = half.core.params.grad, grads[0]
     assert float((gf - 2 * gh).abs().max() / gf.abs().max()) < 1e-4
+
+
+def test_config5_fullsize_dnc_training_step_properties(cuda):
+    """BASELINE config 5's per-GPU shape AT FULL SIZE: DNC 512 x 128, 4 read heads, 64 sequences x 50 frames -> 3250
+    strictly sequential steps, on the memory-partitioned cluster kernels (ntk_dnc_mp_*: 4 workgroups per sequence = every
+    CU, the link streamed through HBM) with the segmented BPTT its 283 GB of records require (re-recording serialised:
+    two cooperative grids of 256 workgroups cannot share the chip).  One whole training step (recorded forward, loss,
+    BPTT, weight-gradient GEMMs): no hand-off times out, everything is finite, two runs are bitwise identical (fixed-order
+    reductions and hand-offs), and duplicating a half batch doubles the un-normalised loss and the gradient
+    (direct_offset_output_with_dnc.py:606-620: the property the data-parallel SUM all-reduce relies on)."""
+    from ntmtrack import tracker
+    B, T = 64, 50
+    g = torch.Generator().manual_seed(14)
+    fmap_h = torch.relu(torch.randn((B // 2 * T, 28, 28, 512), generator=g)).to(cuda)
+    gts_h = torch.rand((B // 2, 64), generator=g).to(cuda)
+    offs_h = (torch.rand((B // 2, T, 2), generator=g) - 0.5).to(cuda)
+    kw = dict(vgg_weights=None, mem_size=512, mem_dim=128, device=cuda, seed=6)
+    half = tracker.DNCOffsetTracker(B // 2, T, **kw)
+    loss_h, _ = half.loss_and_grads(fmap_h, gts_h, offs_h)
+    half.core.check_cluster()
+    assert half.core.last_cluster_form == "mp" and half.core.last_cluster_k == 4 and half.core.last_cluster_bwd_k == 4
+    loss_h, gh = float(loss_h.cpu()), half.core.params.grad.clone()
+    del half
+    torch.cuda.empty_cache()
+    args = (torch.cat([fmap_h, fmap_h]), torch.cat([gts_h, gts_h]), torch.cat([offs_h, offs_h]))
+    grads, losses = [], []
+    for _ in range(2):
+        full = tracker.DNCOffsetTracker(B, T, **kw)
+        assert full.serial_trunk                                  # 64 x 4 workgroups: the trunk pass cannot run beside the core
+        loss_f, _ = full.loss_and_grads(*args)
+        full.core.check_cluster()
+        assert full.core.last_cluster_form == "mp" and full.core.last_cluster_k == 4 and full.core.last_cluster_bwd_k == 4
+        assert full.core.last_segments is not None and full.core.last_rerecord_overlapped is False
+        grads.append(full.core.params.grad.clone())
+        losses.append(float(loss_f.cpu()))
+        del full
+        torch.cuda.empty_cache()
+    assert torch.equal(grads[0], grads[1]) and losses[0] == losses[1], "the config-5 training step is not bitwise reproducible"
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0 and np.isfinite(losses[0])
+    np.testing.assert_allclose(losses[0], 2 * loss_h, rtol=1e-5)
+    assert float((grads[0] - 2 * gh).abs().max() / grads[0].abs().max()) < 1e-4
