@@ -181,6 +181,13 @@ int ntk_ntm_cosine_similarity(const float* memory, const float* keys, float* out
                               int mode, void* stream);
 int ntk_ntm_circular_convolution(const float* w, const float* kernel, float* out, int B, int H, int N, int shift_space,
                                  void* stream);
+/* The intermediate tensors of ONE cell step that NTMCell.__call__ returns in `debug` (ntm_cell.py:230-250) and the fused
+ * step keeps in registers: sw (:161, softmax of the raw shift block at oS), w_gated (:153-156), powed_w_conv (:173), M_write /
+ * M_erase (:197-203), from what the step records
+ * (u [B,ldu] = the activated control vector with g at oG, gamma at oY, erase at oE, add at oA; wc, wv, w, w_prev [B,H,N]). */
+int ntk_ntm_step_debug(const float* u, int ldu, int oG, int oS, int shift_space, int oY, int oE, int oA, const float* wc, const float* wv,
+                       const float* w, const float* w_prev, float* sw, float* w_gated, float* w_conv_powed, float* M_write,
+                       float* M_erase, int B, int N, int Md, int R, int Wh, void* stream);
 
 /* One step of the cell (ntk_ntm_step_fwd/bwd) = the sequence kernels with S = 1; argument meaning as
  * ntk_ntm_seq_fwd / ntk_ntm_seq_bwd (the state AFTER the step takes the place of the final state). */

@@ -70,6 +70,7 @@ def _sig(lib):
         "ntk_dnc_access_step_bwd": (c_int, [P, c_int] + [P] * 14 + [c_int] * 5 + [P]),
         "ntk_ntm_cosine_similarity": (c_int, [P] * 3 + [c_int] * 5 + [P]),
         "ntk_ntm_circular_convolution": (c_int, [P] * 3 + [c_int] * 4 + [P]),
+        "ntk_ntm_step_debug": (c_int, [P] + [c_int] * 7 + [P] * 9 + [c_int] * 5 + [P]),
         "ntk_ntm_step_fwd": (c_int, [c_int] * 9 + [P] * 24),
         "ntk_ntm_step_bwd": (c_int, [c_int] * 9 + [P, c_int, P, c_int] + [P] * 22),
         "ntk_lstm_step_fwd": (c_int, [P, P, ctypes.c_float, P, P, P, c_int, c_int, P]),

@@ -69,7 +69,61 @@ __global__ void circular_convolution_kernel(const float* __restrict__ w, const f
     }
 }
 
+// The intermediate tensors of one NTMCell step that the reference returns in `debug` but the fused step keeps in
+// registers (ntm_cell.py:153-206): w_gated = g wc + (1 - g) w_prev (:153-156), powed_w_conv = w_conv ^ gamma (:173),
+// M_erase = prod_heads (1 - w_write (x) erase) (:197-199), M_write = sum_heads w_write (x) add (:201-203), and the shift weights
+// sw = softmax over the shift space (:161).
+// Inputs are what the step records: g / gamma / erase / add as activated ([B,H], [B,H], [B,Wh,Md], [B,Wh,Md] inside the
+// control vector u with row stride ldu), wc / wv / w [B,H,N], w_prev [B,H,N].
+__global__ __launch_bounds__(256) void step_debug_kernel(const float* __restrict__ u, int ldu, int oG, int oY, int oE, int oA,
+                                                          const float* __restrict__ wc, const float* __restrict__ wv,
+                                                          const float* __restrict__ w, const float* __restrict__ w_prev,
+                                                          float* __restrict__ w_gated, float* __restrict__ powed,
+                                                          float* __restrict__ M_write, float* __restrict__ M_erase,
+                                                          float* __restrict__ sw, int oS, int SS,
+                                                          int N, int Md, int R, int Wh) {
+    const int b = blockIdx.x, H = R + Wh;
+    const float* ub = u + (size_t)b * ldu;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {          // shift weights: softmax over the shift space (:161; u holds the raw values)
+        float mx = -INFINITY, s = 0.f;
+        for (int j = 0; j < SS; ++j) mx = fmaxf(mx, ub[oS + h * SS + j]);
+        for (int j = 0; j < SS; ++j) s += expf(ub[oS + h * SS + j] - mx);
+        for (int j = 0; j < SS; ++j) sw[((size_t)b * H + h) * SS + j] = expf(ub[oS + h * SS + j] - mx) / s;
+    }
+    for (int idx = threadIdx.x; idx < H * N; idx += blockDim.x) {
+        const int h = idx / N;
+        const size_t o = (size_t)b * H * N + idx;
+        const float g = ub[oG + h], gamma = ub[oY + h];
+        w_gated[o] = wc[o] * g + w_prev[o] * (1.0f - g);
+        powed[o] = powf(wv[o], gamma);
+    }
+    for (int idx = threadIdx.x; idx < N * Md; idx += blockDim.x) {
+        const int n = idx / Md, m = idx - n * Md;
+        float er = 1.f, wr = 0.f;
+        for (int j = 0; j < Wh; ++j) {
+            const float ww = w[((size_t)b * H + R + j) * N + n];
+            er *= 1.0f - ww * ub[oE + j * Md + m];
+            wr += ww * ub[oA + j * Md + m];
+        }
+        M_erase[(size_t)b * N * Md + idx] = er;
+        M_write[(size_t)b * N * Md + idx] = wr;
+    }
+}
+
 }  // namespace
+
+extern "C" int ntk_ntm_step_debug(const float* u, int ldu, int oG, int oS, int shift_space, int oY, int oE, int oA, const float* wc, const float* wv,
+                                  const float* w, const float* w_prev, float* sw, float* w_gated, float* w_conv_powed, float* M_write,
+                                  float* M_erase, int B, int N, int Md, int R, int Wh, void* stream) {
+    NTK_REQUIRE(u && wc && wv && w && w_prev && sw && w_gated && w_conv_powed && M_write && M_erase, NTK_ERR_BAD_PTR, "ntk_ntm_step_debug: null pointer");
+    NTK_REQUIRE(oS >= 0 && shift_space > 0 && oS + (R + Wh) * shift_space <= ldu, NTK_ERR_BAD_SHAPE, "ntk_ntm_step_debug: shift block");
+    NTK_REQUIRE(B > 0 && N > 0 && Md > 0 && R >= 0 && Wh > 0 && ldu > 0 && oG >= 0 && oY >= 0 && oE >= 0 && oA + Wh * Md <= ldu, NTK_ERR_BAD_SHAPE,
+                "ntk_ntm_step_debug: B=%d N=%d Md=%d R=%d Wh=%d ldu=%d", B, N, Md, R, Wh, ldu);
+    step_debug_kernel<<<B, 256, 0, (hipStream_t)stream>>>(u, ldu, oG, oY, oE, oA, wc, wv, w, w_prev, w_gated, w_conv_powed, M_write, M_erase,
+                                                         sw, oS, shift_space, N, Md, R, Wh);
+    NTK_CHECK_LAUNCH("ntk_ntm_step_debug");
+    return NTK_OK;
+}
 
 extern "C" int ntk_ntm_cosine_similarity(const float* memory, const float* keys, float* out, int B, int N, int Md, int H,
                                          int mode, void* stream) {

@@ -392,12 +392,28 @@ class NTMCell(object):
         B = inputs.shape[0]
         H, Md, R = d.H, d.Md, d.R
         w = rec["w"][:, 0]
-        debug = {   # ntm_cell.py:230-250 (the reference's key 'bega' is kept)
-            "k": u[:, d.oK:d.oB].reshape(B, H, Md), "bega": u[:, d.oB:d.oG].unsqueeze(-1),
+        k = u[:, d.oK:d.oB].reshape(B, H, Md)
+        # the six tensors the fused step keeps in registers, from HIP kernels on what the step recorded: the similarity is
+        # ops.batched_smooth_cosine_similarity as coded (ntm_cell.py:136, quirk Q1), the other four one elementwise kernel
+        from . import ops as _ops
+        Mp, wp = M_prev.contiguous().float(), w_prev.contiguous().float()
+        similarity = _ops.batched_smooth_cosine_similarity(Mp, k.contiguous(), device=self.device)
+        wc, wv, wcur = rec["wc"][:, 0].contiguous(), rec["wv"][:, 0].contiguous(), w.contiguous()
+        uc = u.contiguous()
+        w_gated, powed = torch.empty_like(wcur), torch.empty_like(wcur)
+        M_write, M_erase = torch.empty_like(Mp), torch.empty_like(Mp)
+        sw = torch.empty((B, H, d.SS), device=self.device)
+        _lib.check(_lib.lib().ntk_ntm_step_debug(_P(uc), uc.shape[1], d.oG, d.oS, d.SS, d.oY, d.oE, d.oA, _P(wc), _P(wv), _P(wcur), _P(wp),
+                                                 _P(sw), _P(w_gated), _P(powed), _P(M_write), _P(M_erase), B, d.N, Md, R, d.Wh,
+                                                 _lib.stream()), "ntk_ntm_step_debug")
+        debug = {   # ntm_cell.py:230-250: all 19 tensors (the reference's key 'bega' is kept)
+            "k": k, "bega": u[:, d.oB:d.oG].unsqueeze(-1),
             "g": u[:, d.oG:d.oS].unsqueeze(-1), "gamma": u[:, d.oY:d.oE].unsqueeze(-1),
             "erase": u[:, d.oE:d.oA].reshape(B, d.Wh, Md), "add": u[:, d.oA:d.P].reshape(B, d.Wh, Md),
-            "w_content_focused": rec["wc"][:, 0], "w_conv": rec["wv"][:, 0],
+            "sw": sw, "similarity": similarity,
+            "w_content_focused": rec["wc"][:, 0], "w_gated": w_gated, "w_conv": rec["wv"][:, 0], "w_conv_powed": powed,
             "w": w, "w_read": w[:, :R], "w_write": w[:, R:], "M": new["M"], "M_prev": M_prev,
+            "M_write": M_write, "M_erase": M_erase,
         }
         state = {"M": new["M"], "w": new["w"], "read": new["read"], "controller_state": new["controller_state"]}
         return (outputs[:, 0], logits[:, 0], state, debug, new["M"], new["w"], new["read"], new["controller_state"])

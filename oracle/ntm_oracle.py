@@ -271,7 +271,7 @@ def ntm_step(cfg, params, x, state):
     new_state = {"M": M, "w": w, "read": read, "controller_state": new_cs}
     debug = {"k": k, "beta": beta, "g": g, "sw": sw, "gamma": gamma, "erase": erase,
              "add": add, "similarity": sim, "w_content_focused": wc, "w_gated": wg,
-             "w_conv": wv, "w_conv_powed": pw, "w": w, "h": h, "u": u}
+             "w_conv": wv, "w_conv_powed": pw, "w": w, "M_write": M_write.astype(dt), "M_erase": M_erase.astype(dt), "h": h, "u": u}
     return out, logit, new_state, debug
 
 

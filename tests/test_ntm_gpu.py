@@ -96,9 +96,20 @@ def test_step_api_8tuple_and_debug(cuda):
     np.testing.assert_allclose(read.cpu().numpy(), new["read"], atol=1e-5)
     np.testing.assert_allclose(cs.cpu().numpy(), new["controller_state"], atol=1e-5)
     assert set(state.keys()) == {"M", "w", "read", "controller_state"}
+    # every one of the 19 tensors of the reference's debug dict (ntm_cell.py:230-250), against the oracle's
+    assert set(debug.keys()) == {"k", "gamma", "add", "erase", "bega", "g", "sw", "similarity", "w_content_focused", "w_gated",
+                                 "w_conv", "w_conv_powed", "w", "w_read", "w_write", "M", "M_prev", "M_write", "M_erase"}
+    R = cfg.read_heads
+    ref = dict(dbg)
+    ref.update(beta=dbg["beta"], w_read=dbg["w"][:, :R], w_write=dbg["w"][:, R:], M=new["M"], M_prev=st["M"])
     for key, okey in (("k", "k"), ("bega", "beta"), ("g", "g"), ("gamma", "gamma"), ("erase", "erase"),
-                      ("add", "add"), ("w_content_focused", "w_content_focused"), ("w_conv", "w_conv"), ("w", "w")):
-        np.testing.assert_allclose(debug[key].cpu().numpy(), dbg[okey], atol=1e-5, err_msg=key)
+                      ("add", "add"), ("sw", "sw"), ("similarity", "similarity"), ("w_content_focused", "w_content_focused"),
+                      ("w_gated", "w_gated"), ("w_conv", "w_conv"), ("w_conv_powed", "w_conv_powed"), ("w", "w"),
+                      ("w_read", "w_read"), ("w_write", "w_write"), ("M", "M"), ("M_prev", "M_prev"), ("M_write", "M_write"),
+                      ("M_erase", "M_erase")):
+        got, want = debug[key].cpu().numpy(), np.asarray(ref[okey])
+        assert got.shape == want.shape, (key, got.shape, want.shape)
+        np.testing.assert_allclose(got, want, atol=1e-5, err_msg=key)
 
 
 def test_zero_state_matches_oracle(cuda):
