@@ -725,8 +725,9 @@ class LoopNTMTracker(object):
 class PlainNTMTracker(object):
     """ntm_tracker_new.py:66-110: the cell statically unrolled ``model_length`` times over [B, model_length, D] inputs,
     nothing assumed about the inputs.  Same call signature; the unrolled graph becomes one persistent kernel launch.
-    Returns (outputs, output_logits, states, debugs): ``states`` holds the initial and the final state (the reference
-    keeps every step's; the per-step memories / head weights are in ``debugs`` = the recorded tensors [B,S,...])."""
+    Returns (outputs, output_logits, states, debugs) as the reference: ``states`` = the initial state followed by the state
+    after EVERY step (model_length + 1 dicts, :95-100; views of the tensors the launch recorded), ``debugs`` = the recorded
+    per-step tensors [B,S,...] (u, wc, wv, w, M, read: the reference's per-step debug dicts side by side)."""
 
     def __init__(self, model_length, output_dim, initializer=None, **kwargs):
         self.model_length = model_length
@@ -743,7 +744,21 @@ class PlainNTMTracker(object):
         state = state or self.cell.zero_state(B, self.initializer)
         logits, outputs, new, rec = self.cell.run_sequence(X, state, record=True)
         debugs = {k: rec[k] for k in ("u", "wc", "wv", "w", "M", "read") if k in rec}
-        return outputs, logits, [state, new], debugs
+        return outputs, logits, [state] + per_step_states(self.cell, rec, new), debugs
+
+
+def per_step_states(cell, rec, final):
+    """The state after every step of a recorded launch, as the reference's state dicts (ntm_cell.py:223-228): M, w, read and
+    controller_state = [c, h] (BasicLSTMCell, state_is_tuple=False; the recorded cell is the step's c, the recorded h its
+    output).  Views / copies of the records only; the last entry is the launch's final state itself."""
+    hid = cell.dims.hid
+    S = rec["M"].shape[1]
+    out = []
+    for t in range(S - 1):
+        out.append({"M": rec["M"][:, t], "w": rec["w"][:, t], "read": rec["read"][:, t],
+                    "controller_state": torch.cat([rec["c"][:, t], rec["h"][:, t, :hid]], dim=1)})
+    out.append(final)
+    return out
 
 
 class NTMTracker(object):
@@ -777,5 +792,5 @@ class NTMTracker(object):
         state = self.cell.zero_state(B, self.initializer)
         logits, outputs, new, rec = self.cell.run_sequence(X, state, record=True)
         debugs = {k: rec[k] for k in ("u", "wc", "wv", "w", "M", "read") if k in rec}
-        return outputs, logits, [state, new], debugs
+        return outputs, logits, [state] + per_step_states(self.cell, rec, new), debugs
 

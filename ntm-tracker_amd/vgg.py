@@ -243,7 +243,10 @@ class VGG16Conv43(object):
             raise _lib.NtkError("frames must be [F,H,W,3] NHWC")
         F, H, W, _ = frames.shape
         if out is None:
-            out = torch.empty((F, H // 8, W // 8, 512), device=frames.device, dtype=torch.float32)
+            # with a features_window the window kernel leaves everything outside the window untouched: the map a caller
+            # gets back must be zero there, not uninitialised memory
+            alloc = torch.zeros if getattr(self, "features_window", None) is not None else torch.empty
+            out = alloc((F, H // 8, W // 8, 512), device=frames.device, dtype=torch.float32)
         for f0 in range(0, F, self.chunk_frames):
             f1 = min(F, f0 + self.chunk_frames)
             n = self.split_streams if (f1 - f0) >= 32 * self.split_streams else 1

@@ -105,17 +105,22 @@ def test_static_unroll_trackers_match_oracle(cuda, two_step):
     cfg = O.NTMConfig(x.shape[2], F + 1, mem_size=64, mem_dim=8, shift_range=1, controller_hidden_size=32, controller_num_layers=1,
                       write_head_size=1, read_head_size=2)
     sd = {k: v.numpy() for k, v in trk.cell.state_dict().items()}
-    out_ref, logits_ref, fin = O.loop_ntm_tracker(cfg, sd, x)
+    out_ref, logits_ref, fin, states_ref = O.loop_ntm_tracker(cfg, sd, x, return_states=True)
     torch.cuda.synchronize()
-    assert logits.shape == (B, x.shape[1], F + 1) and len(states) == 2
+    # ntm_tracker_new.py:95-100: the initial state and the state after EVERY step
+    assert logits.shape == (B, x.shape[1], F + 1) and len(states) == x.shape[1] + 1
     np.testing.assert_allclose(logits.cpu().numpy(), logits_ref, atol=2e-5)
     np.testing.assert_allclose(outputs.cpu().numpy(), out_ref, atol=2e-5)
-    np.testing.assert_allclose(states[1]["M"].cpu().numpy(), fin["M"], atol=2e-5)
+    for t, ref in enumerate(states_ref):
+        for key in ("M", "w", "read", "controller_state"):
+            np.testing.assert_allclose(states[t + 1][key].cpu().numpy(), ref[key], atol=2e-5, err_msg="state %d %s" % (t + 1, key))
+    np.testing.assert_allclose(states[-1]["M"].cpu().numpy(), fin["M"], atol=2e-5)
     assert debugs["M"].shape[:2] == (B, x.shape[1])
     # PlainNTMTracker on the same rows gives the same thing
     plain = PlainNTMTracker(x.shape[1], F + 1, device=cuda, seed=3, **kw)
-    o2, l2, _s, _d = plain(torch.from_numpy(x).to(cuda))
-    assert torch.equal(l2, logits) and torch.equal(o2, outputs)
+    o2, l2, s2, _d = plain(torch.from_numpy(x).to(cuda))
+    assert torch.equal(l2, logits) and torch.equal(o2, outputs) and len(s2) == x.shape[1] + 1
+    assert all(torch.equal(s2[t][key], states[t][key]) for t in range(1, len(s2)) for key in ("M", "w", "read", "controller_state"))
 
 
 def test_two_step_tracker_with_input_compressor_gradients(cuda):

@@ -290,6 +290,13 @@ def test_tracker_features_roi_is_invisible_to_the_recurrent_core(cuda):
         res.append((X.clone(), float(loss.cpu()), trk._flat_grad().clone(), fmap.clone()))
     assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and torch.equal(res[0][2], res[1][2])
     assert not torch.equal(res[0][3], res[1][3])          # the maps themselves differ outside the window (zeros there)
+    # ... and "zeros there" holds for a map the trunk allocates itself (VGG16Conv43.__call__ without `out`): inside the
+    # window the whole-map values, outside exactly zero -- never uninitialised memory
+    full, roi = res[0][3], res[1][3]
+    assert torch.equal(roi[:, 4:24, 4:24], full[:, 4:24, 4:24])
+    outside = roi.clone()
+    outside[:, 4:24, 4:24] = 0
+    assert float(outside.abs().max()) == 0.0
 
 
 def test_vgg_trunk_stream_parts_do_not_change_the_result(cuda):
