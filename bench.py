@@ -43,19 +43,22 @@ def log(msg):
     print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
 
 
-def synth_inputs(B, T, device, seed):
+def synth_inputs(B, T, device, seed, first_sequence=0):
     """SURVEY 8(d) synthetic inputs: frames U[0,255) - VGG_MEAN; frame-0 heat-map =
-    discrete_gauss((.5,.5),(8,8),1); offsets U(-.5,.5), frame 0 = 0."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    discrete_gauss((.5,.5),(8,8),1); offsets U(-.5,.5), frame 0 = 0.
+    Every SEQUENCE of the global batch has its own generator, seeded by (seed, global sequence index): rank r of a
+    data-parallel run, which owns sequences parallel.shard_range(world * B, r, world), generates exactly the rows a single
+    process would hold at those indices."""
     mean = torch.tensor([123.68, 116.78, 103.94])
     frames = torch.empty((B * T, 224, 224, 3), dtype=torch.float32)
-    for i in range(0, B * T, 64):
-        n = min(64, B * T - i)
-        frames[i:i + n] = torch.rand((n, 224, 224, 3), generator=g) * 255.0 - mean
+    offs = torch.empty((B, T, 2), dtype=torch.float32)
+    for b in range(B):
+        g = torch.Generator(device="cpu").manual_seed(seed * 1000003 + first_sequence + b)
+        frames[b * T:(b + 1) * T] = torch.rand((T, 224, 224, 3), generator=g) * 255.0 - mean
+        offs[b] = torch.rand((T, 2), generator=g) - 0.5
     from ntmtrack.geometry import discrete_gauss
     hm = discrete_gauss((.5, .5), (8, 8), 1.0)
     gts0 = torch.from_numpy(np.tile(hm.reshape(1, 64), (B, 1)).astype(np.float32))
-    offs = torch.rand((B, T, 2), generator=g) - 0.5
     offs[:, 0, :] = 0
     return frames.to(device), gts0.to(device), offs.to(device)
 
@@ -343,7 +346,10 @@ def main():
         trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, conv_dtype=args.conv_dtype, conv_algo=args.conv_algo,
                                        features_roi=args.features_roi)   # same init on every rank
     log("tracker built; generating synthetic inputs")
-    frames, gts0, offs = synth_inputs(B, T, dev, 42 + rank)
+    from ntmtrack import parallel
+    lo, hi = parallel.shard_range(world * B, rank, world)          # this rank's sequences of the global batch
+    assert hi - lo == B
+    frames, gts0, offs = synth_inputs(B, T, dev, 42, first_sequence=lo)
     log("inputs resident in HBM: frames %s" % (tuple(frames.shape),))
 
     ev = lambda: torch.cuda.Event(enable_timing=True)

@@ -45,3 +45,31 @@ def test_bench_emits_contract_json(cuda, capsys, monkeypatch, model):
         assert "cluster" in out["memory_step"]["kernel"] and "cluster" in out["memory_step_bptt"]["kernel"]
     # frames/s = frames per step / seconds per step
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2
+
+
+def test_bench_two_ranks_print_one_json_line(cuda, tmp_path):
+    """The N > 1 contract, rehearsed on the one-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+    with NTK_DIST_BACKEND=gloo (both ranks share the device; the driver's run uses nccl = RCCL, one GPU per rank) prints
+    EXACTLY ONE JSON line (rank 0's), with n_gpus 2, the global batch = 2 x the per-GPU batch (weak scaling), and a
+    frames/s value that is the whole job's: both ranks' frames over the max-over-ranks time."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NTK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--seq-len", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert abs(out["value"] - 2 * 2 * 2 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2
+    assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
