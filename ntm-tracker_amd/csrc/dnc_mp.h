@@ -101,6 +101,21 @@ static inline size_t dnc_mp_workspace_bytes(int B, int k, const int* slot) {
     return dnc_mp_ctrl_bytes(B, k) + ((dnc_mp_mbox_floats(B, k, slot) * sizeof(float) + 255) & ~(size_t)255) + 256;
 }
 
+// 16-byte payload loads of a hand-off: raw buffer loads with sc1 (aux 16: the per-CU L1 is bypassed, as the 4- and 8-byte agent-scope
+// loads of cl_load do; MI355X_MICROARCH.md "valid forms": buffer_load_dwordx4 sc1 is one of them).  The consumers of hand-offs B / 1 / 2
+// read 32-80 KB per step: with 4-byte loads that was 5-8 us of a step.  rs: resource over one sequence's [parity][g][slot] region
+// of a hand-off (wave-uniform); offsets in floats, multiples of 4.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mp_rsrc(const float* base, size_t floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(floats * sizeof(float)), 0x00020000);
+}
+__device__ __forceinline__ f32x4 mp_load4(__amdgpu_buffer_rsrc_t rs, int float_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4, 0, 16));
+}
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 mp_load4i(__amdgpu_buffer_rsrc_t rs, int float_off) {
+    return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, float_off * 4, 0, 16));
+}
+
 // wait with its OWN time base (a bound on one stalled exchange, not on the kernel's run time) and a sticky error word
 __device__ __forceinline__ bool mp_wait(const unsigned* flags, unsigned epoch, int k, unsigned* err, unsigned* sticky, int* s_abort, int tid) {
     if (tid < 64) {

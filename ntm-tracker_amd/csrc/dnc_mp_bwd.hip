@@ -78,7 +78,7 @@ constexpr __host__ __device__ DncMpBwdGeo dnc_mp_bwd_geo(const DncMpCfg& c) {
 }
 
 struct DncMpBwdLds {
-    int part, RP, I, DX, WW, WWp, U, Up, Pp, CW, AL, SIMw, DWW, DCW, DA, gP, DPp, gU, gUn, NU, KEY, RANK,
+    int part, RP, NMr, NMw, I, DX, WW, WWp, U, Up, Pp, CW, AL, SIMw, DWW, DCW, DA, gP, DPp, gU, gUn, NU, KEY, RANK,
         RWp, RWt, gRW, G, DRWp, DSIM, SIMr, GZ, DR, DHC, DG, gC, SC, total;
 };
 
@@ -94,6 +94,7 @@ constexpr __host__ __device__ DncMpBwdLds dnc_mp_bwd_lds(const DncMpCfg& c, cons
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
     L.part = take(part);
     L.RP = take(c.NH * (c.R + 1) * c.NR);                              // link pass: per-half row sums
+    L.NMr = take(c.NR); L.NMw = take(c.NR);                            // |M_t[n]|, |M_{t-1}[n]| of the own rows (B2 -> B4, B7 -> B10b)
     L.I = take(c.IP); L.DX = take(c.IP);
     L.WW = take(N); L.WWp = take(N); L.U = take(N); L.Up = take(N); L.Pp = take(N); L.CW = take(N); L.AL = take(N);
     L.SIMw = take(N); L.DWW = take(N); L.DCW = take(N); L.DA = take(N); L.gP = take(N); L.DPp = take(N); L.gU = take(N);
@@ -144,7 +145,7 @@ __device__ __forceinline__ f32x4 mpb_fold4(f32x4 v, int LPR) {
     const int N = C.N, W = C.W, R = C.R, RN = R * N;                                                                          \
     const int hid = C.hid, K = C.K, IP = C.IP, RWd = R * W, N4 = C.N4, W4 = C.W4;                                             \
     const int row0 = g * NR, u0 = min(hid, g * upk), u1 = min(hid, u0 + upk), nU = u1 - u0;                                   \
-    float* sPart = smem + L.part; float* sRP = smem + L.RP;                                                                   \
+    float* sPart = smem + L.part; float* sRP = smem + L.RP; float* sNMr = smem + L.NMr; float* sNMw = smem + L.NMw;           \
     float* sI = smem + L.I; float* sDX = smem + L.DX;                                                                         \
     float* sWW = smem + L.WW; float* sWWp = smem + L.WWp; float* sU = smem + L.U; float* sUp = smem + L.Up;                   \
     float* sPp = smem + L.Pp; float* sCW = smem + L.CW; float* sAL = smem + L.AL; float* sSIMw = smem + L.SIMw;               \
@@ -156,7 +157,7 @@ __device__ __forceinline__ f32x4 mpb_fold4(f32x4 v, int LPR) {
     float* sDSIM = smem + L.DSIM; float* sSIMr = smem + L.SIMr;                                                               \
     float* sGZ = smem + L.GZ; float* sDR = smem + L.DR; float* sDHC = smem + L.DHC; float* sDG = smem + L.DG;                 \
     float* sgC = smem + L.gC; float* sSC = smem + L.SC; int* sAbort = reinterpret_cast<int*>(sSC + 120);                       \
-    (void)k; (void)K; (void)IP; (void)RWd; (void)N4; (void)W4; (void)u1; (void)nU; (void)RN; (void)sPart; (void)sRP;          \
+    (void)k; (void)K; (void)IP; (void)RWd; (void)N4; (void)W4; (void)u1; (void)nU; (void)RN; (void)sPart; (void)sRP; (void)sNMr; (void)sNMw; \
     (void)sI; (void)sDX; (void)sWW; (void)sWWp; (void)sU; (void)sUp; (void)sPp; (void)sCW; (void)sAL; (void)sSIMw;            \
     (void)sDWW; (void)sDCW; (void)sDA; (void)sgP; (void)sDPp; (void)sgU; (void)sgUn; (void)sNU; (void)sKEY; (void)sRank;      \
     (void)sRWp; (void)sRWt; (void)sgRW; (void)sG; (void)sDRWp; (void)sDSIM; (void)sSIMr; (void)sGZ; (void)sDR; (void)sDHC; (void)sDG;     \
@@ -182,9 +183,11 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
     const int S = a0.S;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 
-    // register-resident d(memory) and memory rows of the current step: lane gl of group grp holds float4 column gl of the
-    // own rows grp + NG q
-    f32x4 gMr[MPQ], Mt[MPQ];
+    // register-resident d(memory): lane gl of group grp holds float4 column gl of the own rows grp + NG q.  The memory rows
+    // (M_t for B2 / B4, then M_{t-1} for B7 / B10b) are requested from the records where a step needs them, all rows of a
+    // thread in one batch: carried over from the previous iteration they sat in registers through the link pass, the compiler
+    // spilled them there and reloaded them one dependent scratch load at a time (6 us of a step in B10b alone).
+    f32x4 gMr[MPQ], Mt[MPQ], Mp[MPQ];
 
     // ---- carried gradients: zero (the loss depends on the outputs only) or what the following segment left behind
     {
@@ -200,17 +203,13 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         for (int i = tid0; i < RN; i += CT) sgRW[i] = cin ? cy[2 * N + i] : 0.f;
         for (int i = tid0; i < Q.ldkT; i += CT) sGZ[i] = (cin && i < K) ? cy[2 * N + RN + i] : 0.f;
         for (int i = tid0; i < nU; i += CT) sgC[i] = cin ? cy[2 * N + RN + Q.ldkT + u0 + i] : 0.f;
-        const size_t btl = (size_t)b * S + (S - 1);
         const int gl0 = tid0 & (Q.LPR - 1), grp0 = tid0 / Q.LPR;
 #pragma unroll
         for (int q = 0; q < MPQ; ++q) {
             gMr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             Mt[q] = gMr[q];
             const int nl = grp0 + Q.NG * q;
-            if (q < Q.NQ && nl < NR && gl0 < W4) {
-                gMr[q] = reinterpret_cast<const f32x4*>(a.gM + ((size_t)b * N + row0 + nl) * W)[gl0];
-                Mt[q] = reinterpret_cast<const f32x4*>(a.rec_M + (btl * N + row0 + nl) * W)[gl0];
-            }
+            if (q < Q.NQ && nl < NR && gl0 < W4) gMr[q] = reinterpret_cast<const f32x4*>(a.gM + ((size_t)b * N + row0 + nl) * W)[gl0];
         }
     }
     __syncthreads();
@@ -266,6 +265,23 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         float* slot4 = mb4 + ((size_t)par * k + g) * sl4;
 
         MP_STAMP(0);       // loop top
+        // Memory rows in registers: Mt = own rows of M_t (B2, B4), Mp = own rows of M_{t-1} (B7; requested again behind hand-off 2
+        // for B10b, then carried over as the next step's Mt).  The next step's Mp is requested right after B10b, so a step
+        // starts with both in place; only the first step of a launch loads them here.
+        const float* Mpg = (t > 0) ? a.rec_M + ((bt - 1) * N + row0) * W : a.mem0 + ((size_t)b * N + row0) * W;
+        if (t == S - 1) {
+            const float* Mtg = a.rec_M + (bt * N + row0) * W;
+#pragma unroll
+            for (int q = 0; q < MPQ; ++q) {
+                const int nl = grp + NG * q;
+                Mt[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Mp[q] = Mt[q];
+                if (q < NQ && nl < NR && gl < W4) {
+                    Mt[q] = reinterpret_cast<const f32x4*>(Mtg + (size_t)nl * W)[gl];
+                    Mp[q] = reinterpret_cast<const f32x4*>(Mpg + (size_t)nl * W)[gl];
+                }
+            }
+        }
         // ------------------------------------------------------------ this step's records -> LDS
         float pf_cr[8], pf_fv[8], pf_bv[8];                   // B3: wave i < R, slots lane + 64 j
         {
@@ -341,7 +357,6 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         __syncthreads();
         MP_STAMP(1);       // records -> LDS, B1, key norms, rank partial
         // ------------------------------------------------------------ B2: pass 1 over M_t (registers): d(rw) through the reads, read-key scores
-        float nmr[MPQ];                                       // |M_t[n]| of the rows of this group
         {
             f32x4 dr[4], kr[4];
 #pragma unroll
@@ -355,13 +370,12 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
 #pragma unroll
             for (int q = 0; q < MPQ; ++q) {
-                nmr[q] = 1.f;
                 if (q < NQ) {
                     const int nl = grp + NG * q;
                     const bool rok = nl < NR;
                     const f32x4 m = Mt[q];
                     const float nm = cl_sqrt(group_sum_rt(mpb_dot4(m, m), LPR) + EPS);
-                    nmr[q] = nm;
+                    if (gl == 0 && rok) sNMr[nl] = nm;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (i < R) {
@@ -391,22 +405,23 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         MP_STAMP(3);       // publish 1 + gate record requests
         if (!mp_wait(fl1, epoch, k, a.err, a.sticky, sAbort, tid)) return;
         MP_STAMP(4);       // wait 1
-        {   // consume hand-off 1: G and the read-key scores of every slot; ranks
-            const float* base = mb1 + (size_t)par * k * sl1;
-            for (int idx = tid; idx < RN; idx += CT) {
+        {   // consume hand-off 1: G and the read-key scores of every slot; ranks (16-byte loads: four consecutive slots per thread)
+            const __amdgpu_buffer_rsrc_t rs = mp_rsrc(mb1 + (size_t)par * k * sl1, (size_t)k * sl1);
+            for (int i4 = tid; i4 < (RN >> 2); i4 += CT) {
+                const int idx = 4 * i4;
                 const int i = cl_div(idx, C.mg_N), n = idx - i * N;
                 const int og = cl_div(n, C.mg_NR), rl = n - og * NR;
-                sG[idx] = cl_load(base + (size_t)og * sl1 + i * NR + rl);
-                sSIMr[idx] = cl_load(base + (size_t)og * sl1 + (R + i) * NR + rl);
+                *reinterpret_cast<f32x4*>(sG + idx) = mp_load4(rs, og * sl1 + i * NR + rl);
+                *reinterpret_cast<f32x4*>(sSIMr + idx) = mp_load4(rs, og * sl1 + (R + i) * NR + rl);
             }
-            for (int n = tid; n < N; n += CT) {
-                float pv[8];
+            for (int n4 = tid; n4 < N4; n4 += CT) {
+                i32x4 rk = {0, 0, 0, 0};
+                i32x4 pv[8];
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? cl_load(base + (size_t)gg * sl1 + 2 * R * NR + n) : 0.f;
-                int rk = 0;
+                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? mp_load4i(rs, gg * sl1 + 2 * R * NR + 4 * n4) : rk;
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) if (gg < k) rk += __float_as_int(pv[gg]);
-                sRank[n] = rk;
+                for (int gg = 0; gg < 8; ++gg) if (gg < k) rk += pv[gg];
+                *reinterpret_cast<i32x4*>(sRank + 4 * n4) = rk;
             }
         }
         __syncthreads();
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 if (q < NQ && nl < NR && gl < W4) {
                     const int n = row0 + nl;
                     const f32x4 m = Mt[q];
-                    const float nm = nmr[q];
+                    const float nm = sNMr[nl];
                     f32x4 gq = gMr[q];
                     float dnm = 0.f;
 #pragma unroll
@@ -520,20 +535,62 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
         }
         MP_STAMP(7);       // B4 + its column sums
-        // M_t is dead from here: its registers take the own memory rows of step t-1 (requested now, first used in B7)
+        __syncthreads();                                      // sPart free again
+        // ------------------------------------------------------------ B7: write backward over (dM, M_{t-1}) of the own rows; write-key scores
         {
-            const float* Mpg = (t > 0) ? a.rec_M + ((bt - 1) * N + row0) * W : a.mem0 + ((size_t)b * N + row0) * W;
+            f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accV = accE;
+            f32x4 ep = {0.f, 0.f, 0.f, 0.f}, vp = ep, kp = ep;
+            if (gl < W4) {
+                ep = *reinterpret_cast<const f32x4*>(sI + C.oE + gl * 4);
+                vp = *reinterpret_cast<const f32x4*>(sI + C.oV + gl * 4);
+                const float* kq = sI + C.oKw + gl * 4;
+                kp = f32x4{kq[0], kq[1], kq[2], kq[3]};
+            }
+            const float nkw = sSC[R];
 #pragma unroll
             for (int q = 0; q < MPQ; ++q) {
-                const int nl = grp + NG * q;
                 if (q < NQ) {
-                    Mt[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (nl < NR && gl < W4) Mt[q] = reinterpret_cast<const f32x4*>(Mpg + (size_t)nl * W)[gl];
+                    const int nl = grp + NG * q;
+                    const bool rok = nl < NR;
+                    const f32x4 mp = Mp[q];
+                    const float wwn = rok ? sWW[row0 + nl] : 0.f;
+                    f32x4 gq = gMr[q];
+                    float t1 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t1 += gq[e] * (vp[e] - mp[e] * ep[e]);
+                        accE[e] -= gq[e] * mp[e] * wwn;
+                        accV[e] += gq[e] * wwn;
+                        gq[e] = gq[e] * (1.0f - wwn * ep[e]);
+                    }
+                    gMr[q] = gq;                                   // now d(M_{t-1}) (content part added in B10b)
+                    t1 = group_sum_rt(t1, LPR);
+                    const float dot = group_sum_rt(mpb_dot4(kp, mp), LPR);
+                    const float nm = cl_sqrt(group_sum_rt(mpb_dot4(mp, mp), LPR) + EPS);
+                    if (gl == 0 && rok) {
+                        sNMw[nl] = nm;
+                        cl_store(slot2 + Q.oT1 + nl, t1, plain);
+                        cl_store(slot2 + Q.oSimw + nl, dot * cl_rcp(nkw * nm + EPS), plain);
+                    }
                 }
+            }
+            accE = mpb_fold4(accE, LPR);
+            accV = mpb_fold4(accV, LPR);
+            if (lane < LPR && gl < W4) {
+                *reinterpret_cast<f32x4*>(sPart + (wave * 2 + 0) * W + gl * 4) = accE;
+                *reinterpret_cast<f32x4*>(sPart + (wave * 2 + 1) * W + gl * 4) = accV;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 2 * W; idx += CT) {
+                const int which = idx / W, w = idx - which * W;
+                float s = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < CW; ++wv) s += sPart[(wv * 2 + which) * W + w];
+                cl_store(slot2 + (which ? Q.oV : Q.oE) + w, s, plain);
             }
         }
         __syncthreads();                                      // sPart free again
-        MP_STAMP(8);       // M_{t-1} requests
+        MP_STAMP(8);       // B7 (before the link pass: the memory rows need not live through it)
         // ------------------------------------------------------------ B5: link pass over the own rows (d(link), L_t, L_{t-1}: HBM streams)
         {
             const int NH = C.NH, RG = Q.RG, NP = Q.NP;
@@ -643,114 +700,79 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             __syncthreads();
         }
         MP_STAMP(10);      // B5 column reductions
-        // ------------------------------------------------------------ B7: write backward over (dM, M_{t-1}) of the own rows; write-key scores
-        float nmw[MPQ];
-        {
-            f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accV = accE;
-            f32x4 ep = {0.f, 0.f, 0.f, 0.f}, vp = ep, kp = ep;
-            if (gl < W4) {
-                ep = *reinterpret_cast<const f32x4*>(sI + C.oE + gl * 4);
-                vp = *reinterpret_cast<const f32x4*>(sI + C.oV + gl * 4);
-                const float* kq = sI + C.oKw + gl * 4;
-                kp = f32x4{kq[0], kq[1], kq[2], kq[3]};
-            }
-            const float nkw = sSC[R];
-#pragma unroll
-            for (int q = 0; q < MPQ; ++q) {
-                nmw[q] = 1.f;
-                if (q < NQ) {
-                    const int nl = grp + NG * q;
-                    const bool rok = nl < NR;
-                    const f32x4 mp = Mt[q];
-                    const float wwn = rok ? sWW[row0 + nl] : 0.f;
-                    f32x4 gq = gMr[q];
-                    float t1 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        t1 += gq[e] * (vp[e] - mp[e] * ep[e]);
-                        accE[e] -= gq[e] * mp[e] * wwn;
-                        accV[e] += gq[e] * wwn;
-                        gq[e] = gq[e] * (1.0f - wwn * ep[e]);
-                    }
-                    gMr[q] = gq;                                   // now d(M_{t-1}) (content part added in B10b)
-                    t1 = group_sum_rt(t1, LPR);
-                    const float dot = group_sum_rt(mpb_dot4(kp, mp), LPR);
-                    const float nm = cl_sqrt(group_sum_rt(mpb_dot4(mp, mp), LPR) + EPS);
-                    nmw[q] = nm;
-                    if (gl == 0 && rok) {
-                        cl_store(slot2 + Q.oT1 + nl, t1, plain);
-                        cl_store(slot2 + Q.oSimw + nl, dot * cl_rcp(nkw * nm + EPS), plain);
-                    }
-                }
-            }
-            accE = mpb_fold4(accE, LPR);
-            accV = mpb_fold4(accV, LPR);
-            if (lane < LPR && gl < W4) {
-                *reinterpret_cast<f32x4*>(sPart + (wave * 2 + 0) * W + gl * 4) = accE;
-                *reinterpret_cast<f32x4*>(sPart + (wave * 2 + 1) * W + gl * 4) = accV;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < 2 * W; idx += CT) {
-                const int which = idx / W, w = idx - which * W;
-                float s = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < CW; ++wv) s += sPart[(wv * 2 + which) * W + w];
-                cl_store(slot2 + (which ? Q.oV : Q.oE) + w, s, plain);
-            }
-        }
         MP_STAMP(11);      // B7
         cl_publish(fl2 + g, epoch, tid, plain);
+        // M_{t-1} rows again, for B10b: requested here (L2 hits, behind the wait), not kept in registers through the link pass
+#pragma unroll
+        for (int q = 0; q < MPQ; ++q) {
+            const int nl = grp + NG * q;
+            Mp[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < NQ && nl < NR && gl < W4) Mp[q] = reinterpret_cast<const f32x4*>(Mpg + (size_t)nl * W)[gl];
+        }
         if (!mp_wait(fl2, epoch, k, a.err, a.sticky, sAbort, tid)) return;
         MP_STAMP(12);      // publish 2 + wait 2
-        {   // consume hand-off 2
-            const float* base = mb2 + (size_t)par * k * sl2;
-            for (int idx = tid; idx < RN; idx += CT) {
+        {   // consume hand-off 2 (16-byte loads; the order of every sum is fixed: owner's row sum, then workgroups 0..k-1)
+            const __amdgpu_buffer_rsrc_t rs = mp_rsrc(mb2 + (size_t)par * k * sl2, (size_t)k * sl2);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            for (int i4 = tid; i4 < (RN >> 2); i4 += CT) {
+                const int idx = 4 * i4;
                 const int i = cl_div(idx, C.mg_N), n = idx - i * N;
                 const int og = cl_div(n, C.mg_NR), rl = n - og * NR;
-                float pv[8];
+                f32x4 pv[8];
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? cl_load(base + (size_t)gg * sl2 + Q.oColRW + idx) : 0.f;
-                float s = cl_load(base + (size_t)og * sl2 + i * NR + rl);
+                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? mp_load4(rs, gg * sl2 + Q.oColRW + idx) : z4;
+                f32x4 s = mp_load4(rs, og * sl2 + i * NR + rl);
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) if (gg < k) s += pv[gg];
-                sDRWp[idx] = s;
+                *reinterpret_cast<f32x4*>(sDRWp + idx) = s;
             }
-            for (int n = tid; n < N; n += CT) {
+            for (int n4 = tid; n4 < N4; n4 += CT) {
+                const int n = 4 * n4;
                 const int og = cl_div(n, C.mg_NR), rl = n - og * NR;
-                float pw[8], pp[8];
+                f32x4 pw[8], pp[8];
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) {
-                    pw[gg] = (gg < k) ? cl_load(base + (size_t)gg * sl2 + Q.oColWW + n) : 0.f;
-                    pp[gg] = (gg < k) ? cl_load(base + (size_t)gg * sl2 + Q.oColP + n) : 0.f;
+                    pw[gg] = (gg < k) ? mp_load4(rs, gg * sl2 + Q.oColWW + n) : z4;
+                    pp[gg] = (gg < k) ? mp_load4(rs, gg * sl2 + Q.oColP + n) : z4;
                 }
-                float sw = cl_load(base + (size_t)og * sl2 + Q.oRowWW + rl), sp = 0.f;
+                f32x4 sw = mp_load4(rs, og * sl2 + Q.oRowWW + rl), sp = z4;
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) if (gg < k) { sw += pw[gg]; sp += pp[gg]; }
-                sDWW[n] = sw + cl_load(base + (size_t)og * sl2 + Q.oT1 + rl);
-                sDPp[n] = sp;
-                sSIMw[n] = cl_load(base + (size_t)og * sl2 + Q.oSimw + rl);
+                *reinterpret_cast<f32x4*>(sDWW + n) = sw + mp_load4(rs, og * sl2 + Q.oT1 + rl);
+                *reinterpret_cast<f32x4*>(sDPp + n) = sp;
+                *reinterpret_cast<f32x4*>(sSIMw + n) = mp_load4(rs, og * sl2 + Q.oSimw + rl);
             }
             // column sums of the memory passes -> interface gradients (d read keys, d erase, d write vector)
             if (tid < 4) {
                 float s = 0.f;
+                const float* base = mb2 + (size_t)par * k * sl2;
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) if (gg < k) s += cl_load(base + (size_t)gg * sl2 + Q.oNk + tid);
                 sSC[40 + tid] = s;                                 // d|kr_i|
             }
             __syncthreads();
-            for (int idx = tid; idx < RWd + 2 * W; idx += CT) {
+            for (int i4 = tid; i4 < ((RWd + 2 * W) >> 2); i4 += CT) {
+                const int idx = 4 * i4;
                 const int off = (idx < RWd) ? Q.oK + idx : ((idx < RWd + W) ? Q.oE + (idx - RWd) : Q.oV + (idx - RWd - W));
-                float s = 0.f;
+                f32x4 s = z4;
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) if (gg < k) s += cl_load(base + (size_t)gg * sl2 + off);
+                for (int gg = 0; gg < 8; ++gg) if (gg < k) s += mp_load4(rs, gg * sl2 + off);
                 if (idx < RWd) {
-                    const int i = idx / W;
-                    sDX[C.oKr + idx] = s + sSC[40 + i] * sI[C.oKr + idx] / sSC[i];
+                    const int i = cl_div(i4, C.mg_W4);
+                    const f32x4 kv = *reinterpret_cast<const f32x4*>(sI + C.oKr + idx);
+                    const float dn = sSC[40 + i], rn = sSC[i];
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = s[e] + dn * kv[e] / rn;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sDX[C.oKr + idx + e] = o[e];
                 } else if (idx < RWd + W) {
-                    const float e = sI[C.oE + (idx - RWd)];
-                    sDX[C.oE + (idx - RWd)] = s * e * (1.0f - e);
+                    const f32x4 ev = *reinterpret_cast<const f32x4*>(sI + C.oE + (idx - RWd));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sDX[C.oE + (idx - RWd) + e] = s[e] * ev[e] * (1.0f - ev[e]);
                 } else {
-                    sDX[C.oV + (idx - RWd - W)] = s;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sDX[C.oV + (idx - RWd - W) + e] = s[e];
                 }
             }
         }
@@ -851,8 +873,8 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 const int nl = grp + NG * q;
                 if (q < NQ && nl < NR && gl < W4) {
                     const int n = row0 + nl;
-                    const f32x4 mp = Mt[q];
-                    const float nm = nmw[q];
+                    const f32x4 mp = Mp[q];
+                    const float nm = sNMw[nl];
                     const float dsim = sDCW[n] * bw;
                     const float D = nk * nm + EPS;
                     const float dot = sSIMw[n] * D;
@@ -864,12 +886,24 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                     accKw += ddot * mp;
                 }
             }
+            MP_STAMP(21);      // B10b rows
+            {   // hand the rows over to the next step: its M_t is this step's M_{t-1}; its M_{t-1} is requested now
+                const float* Mqg = (t > 1) ? a.rec_M + ((bt - 2) * N + row0) * W : a.mem0 + ((size_t)b * N + row0) * W;
+#pragma unroll
+                for (int q = 0; q < MPQ; ++q) {
+                    const int nl = grp + NG * q;
+                    Mt[q] = Mp[q];
+                    if (t > 0 && q < NQ && nl < NR && gl < W4) Mp[q] = reinterpret_cast<const f32x4*>(Mqg + (size_t)nl * W)[gl];
+                }
+            }
             accKw = mpb_fold4(accKw, LPR);
             accNkw = mpb_fold(accNkw, LPR);
+            MP_STAMP(22);      // B10b fold
             __syncthreads();                                       // sT / sS (sPart) are dead
             if (lane < LPR && gl < W4) *reinterpret_cast<f32x4*>(sPart + wave * W + gl * 4) = accKw;
             if (lane == 0) sSC[20 + wave] = accNkw;
         }
+        MP_STAMP(23);      // B10b park
         // ------------------------------------------------------------ B11: usage backward (addressing.py:342-374)
         {
             float fgv[4];
@@ -913,7 +947,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
             }
             cl_publish(fl3 + g, epoch, tid, plain);
         }
-        if (wave < R) {                                                          // d(free gates): in the shadow of the hand-off
+        if (wave < R) {                                                          // d(free gates)
             const int i = wave;
             float s = 0.f;
             for (int n = lane; n < N; n += 64) s += sDSIM[i * N + n];
@@ -923,7 +957,30 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         }
         for (int i = tid; i < RN; i += CT) sgRW[i] = sDRWp[i];                  // carried d(read weights_{t-1})
         for (int n = tid; n < N; n += CT) sgP[n] = sDPp[n];                     // carried d(precedence_{t-1})
+        __syncthreads();
         MP_STAMP(16);      // publish 3, free gates, carried vectors
+        // ------------------------------------------------------------ B14: d(clipped h) of the own units += d(interface) . Wi^T
+        //   Wi is [unit][IP]: a row is contiguous -- EIGHT LANES per own unit walk its row (128-byte segments; one unit per thread
+        //   read 64 different rows per load instruction).  Every interface gradient except the write key's is final here, so
+        //   that part of the product runs IN THE SHADOW of hand-off 3; only the write key's columns wait for it.
+        float dh_acc[2] = {0.f, 0.f};                                           // own units tid / 8 and 64 + tid / 8
+        const int l8 = tid & 7;
+        {
+            const f32x4* dx4 = reinterpret_cast<const f32x4*>(sDX);
+            const int kw0 = C.oKw >> 2, kw1 = (C.oKw + W + 3) >> 2;            // float4 columns that hold a write-key entry
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int ju = (tid >> 3) + 64 * p2;
+                if (ju < nU) {
+                    const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wi) + (size_t)(u0 + ju) * C.icg;
+                    const int c1 = kw1 + ((l8 - kw1) & 7);             // first column >= kw1 of this lane's residue class
+#pragma unroll 8
+                    for (int c = l8; c < kw0; c += 8) dh_acc[p2] += mpb_dot4(dx4[c], wp[c]);
+#pragma unroll 8
+                    for (int c = c1; c < C.icg; c += 8) dh_acc[p2] += mpb_dot4(dx4[c], wp[c]);
+                }
+            }
+        }
         if (!mp_wait(fl3, epoch, k, a.err, a.sticky, sAbort, tid)) return;
         {
             const float* base = mb3 + (size_t)par * k * sl3;
@@ -939,27 +996,26 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
         }
         __syncthreads();
         if (g == 0) for (int c = tid; c < IP; c += CT) a.dxi[bt * IP + c] = sDX[c];
-
         MP_STAMP(17);      // wait 3 + consume + dxi out
-        // ------------------------------------------------------------ B14: d(clipped h) of the own units += d(interface) . Wi^T
-        if (tid < Q.nslH * upk) {
-            const int sl = cl_div(tid, C.mg_upk), j = tid - sl * upk;
-            float acc = 0.f;
-            if (j < nU) {
-                const int c0 = sl * Q.cperH, c1 = min(C.icg, c0 + Q.cperH);
-                const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wi) + (size_t)(u0 + j) * C.icg;
-                const f32x4* dx4 = reinterpret_cast<const f32x4*>(sDX);
-#pragma unroll 4
-                for (int c = c0; c < c1; ++c) acc += mpb_dot4(dx4[c], wp[c]);
+        {
+            const f32x4* dx4 = reinterpret_cast<const f32x4*>(sDX);
+            const int kw0 = C.oKw >> 2, kw1 = (C.oKw + W + 3) >> 2;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int ju = (tid >> 3) + 64 * p2;
+                if (ju < nU) {
+                    const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wi) + (size_t)(u0 + ju) * C.icg;
+                    for (int c = kw0 + l8; c < kw1; c += 8) dh_acc[p2] += mpb_dot4(dx4[c], wp[c]);
+                }
+                const float tot = group_sum<8>(dh_acc[p2]);
+                if (ju < nU && l8 == 0) sPart[ju] = tot;
             }
-            sPart[sl * upk + j] = acc;
         }
         __syncthreads();
         // ------------------------------------------------------------ B15: clip + snt.LSTM backward of the own units
         if (tid < nU) {
             const int u = u0 + tid;
-            float dh = sDHC[u];
-            for (int sl = 0; sl < Q.nslH; ++sl) dh += sPart[sl * upk + tid];
+            const float dh = sDHC[u] + sPart[tid];
             const f32x4 gg = pf_gates;
             const float gi = gg[0], gj = gg[1], gf = gg[2], go = gg[3];
             const float c2 = pf_c;
@@ -987,7 +1043,7 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                 const int sl = cl_div(tid, Q.mg_kg4), cg = tid - sl * kg4;
                 const int r0 = sl * Q.nperZ, r1 = min(nrow, r0 + Q.nperZ);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (r0 < r1) acc = ntk_stream_matvec<4>(reinterpret_cast<const f32x4*>(a.WrT) + (size_t)(4 * u0) * kg4 + cg, kg4, sDG, r0, r1, nrow - 1);
+                if (r0 < r1) acc = ntk_stream_matvec<FIX ? 8 : 4>(reinterpret_cast<const f32x4*>(a.WrT) + (size_t)(4 * u0) * kg4 + cg, kg4, sDG, r0, r1, nrow - 1);
                 *reinterpret_cast<f32x4*>(sPart + sl * Q.ldkT + cg * 4) = acc;
             }
             __syncthreads();
@@ -1065,7 +1121,7 @@ static int dnc_mp_bwd_pick(int B, int N, int W, int R, int Wn, int hid, int O, i
         if (NR * k != N || NR < 8 || (NR % 8) != 0) continue;
         c = dnc_mp_cfg(N, W, R, hid, O, k);
         q = dnc_mp_bwd_geo(c);
-        if (c.upk > CT || q.NQ > MPQ || q.kg4 > CT || c.icg > 4 * CT) continue;
+        if (c.upk > 128 || q.NQ > MPQ || q.kg4 > CT || c.icg > 4 * CT) continue;      // B14: two passes of 64 own units
         const DncMpBwdLds L = dnc_mp_bwd_lds(c, q);
         const size_t bytes = (size_t)L.total * sizeof(float);
         if (bytes > 160 * 1024) continue;

@@ -279,19 +279,26 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
                 const int gg = cl_div(u, C.mg_upk);
                 sZ[RWd + u] = cl_load(base + (size_t)gg * sl0 + (u - gg * upk));
             }
-            for (int c = tid; c < IP; c += CT) {
-                float pv[8];
+            const __amdgpu_buffer_rsrc_t rs = mp_rsrc(base, (size_t)k * sl0);
+            for (int c4 = tid; c4 < (IP >> 2); c4 += CT) {          // 16-byte loads: four interface columns per thread
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 pv[8];
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? cl_load(base + (size_t)gg * sl0 + upkp + c) : 0.f;
-                float v = a.Wi[(size_t)hid * IP + c];
+                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? mp_load4(rs, gg * sl0 + upkp + 4 * c4) : z4;
+                f32x4 v4 = reinterpret_cast<const f32x4*>(a.Wi + (size_t)hid * IP)[c4];
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) if (gg < k) v += pv[gg];
-                float r = v;
-                if (c >= C.oE && c < C.oRm) r = dnc_sigmoid(v);                      // erase, free, alloc, write gates
-                else if ((c >= C.oBw && c < C.oKr) || (c >= C.oBr && c < C.I)) r = dnc_softplus(v);   // strengths
-                sI[c] = r;
-                if (c >= C.oKw && c < C.oBw) sK[c - C.oKw] = r;
-                else if (c >= C.oKr && c < C.oBr) sK[W + (c - C.oKr)] = r;
+                for (int gg = 0; gg < 8; ++gg) if (gg < k) v4 += pv[gg];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * c4 + e;
+                    const float v = v4[e];
+                    float r = v;
+                    if (c >= C.oE && c < C.oRm) r = dnc_sigmoid(v);                      // erase, free, alloc, write gates
+                    else if ((c >= C.oBw && c < C.oKr) || (c >= C.oBr && c < C.I)) r = dnc_softplus(v);   // strengths
+                    sI[c] = r;
+                    if (c >= C.oKw && c < C.oBw) sK[c - C.oKw] = r;
+                    else if (c >= C.oKr && c < C.oBr) sK[W + (c - C.oKr)] = r;
+                }
             }
         }
         __syncthreads();
@@ -390,17 +397,20 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
         {
             const float* base = mbA + (size_t)par * k * slA;
             float* sT = sPart;
-            for (int n = tid; n < N; n += CT) {
+            const __amdgpu_buffer_rsrc_t rs = mp_rsrc(base, (size_t)k * slA);
+            for (int n4 = tid; n4 < N4; n4 += CT) {
+                const int n = 4 * n4;
                 const int og = cl_div(n, C.mg_NR);
-                float pv[8];
+                i32x4 rk = {0, 0, 0, 0};
+                i32x4 pv[8];
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? cl_load(base + (size_t)gg * slA + NR + n) : 0.f;
-                sCW[n] = cl_load(base + (size_t)og * slA + (n - og * NR));
-                int rk = 0;
+                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? mp_load4i(rs, gg * slA + NR + n) : rk;
+                *reinterpret_cast<f32x4*>(sCW + n) = mp_load4(rs, og * slA + (n - og * NR));
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) if (gg < k) rk += __float_as_int(pv[gg]);
-                sRank[n] = rk;
-                sT[rk] = 1.0f - sNU[n];                    // sorted_usage = 1 - sorted_nonusage (addressing.py:398)
+                for (int gg = 0; gg < 8; ++gg) if (gg < k) rk += pv[gg];
+                *reinterpret_cast<i32x4*>(sRank + n) = rk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sT[rk[e]] = 1.0f - sNU[n + e];      // sorted_usage = 1 - sorted_nonusage (addressing.py:398)
             }
             __syncthreads();
             if (wave == CW - 1) mp_softmax_row(sCW, N, lane);
@@ -577,43 +587,39 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
         // ------------------------------------------------------------ P8: read weights, precedence, reads
         {
             const float* base = mbB + (size_t)par * k * slB;
-            float fw_[4], bw_[4];
+            // 16-byte loads: a thread = four consecutive slots of one head (R * N / 4 quads over the 512 threads)
+            const __amdgpu_buffer_rsrc_t rs = mp_rsrc(base, (size_t)k * slB);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 fw_ = z4, bw_ = z4;
+            const int q4 = tid;                                        // R * N / 4 <= 512 (R <= 4, N <= 512)
+            const bool qok = q4 < ((R * N) >> 2);
+            int qi = 0, qn = 0;
+            if (qok) {
+                const int idx = 4 * q4;
+                qi = cl_div(idx, C.mg_N); qn = idx - qi * N;
+                const int og = cl_div(qn, C.mg_NR), rl = qn - og * NR;
+                f32x4 pv[8];
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) {
-                fw_[jn] = 0.f; bw_[jn] = 0.f;
-                const int idx = tid + jn * CT;
-                if (jn < C.RNP && idx < R * N) {
-                    const int i = cl_div(idx, C.mg_N), n = idx - i * N;
-                    const int og = cl_div(n, C.mg_NR), rl = n - og * NR;
-                    float pv[8];
+                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? mp_load4(rs, gg * slB + 2 * R * NR + idx) : z4;
+                fw_ = mp_load4(rs, og * slB + qi * NR + rl);
+                *reinterpret_cast<f32x4*>(sCR + idx) = mp_load4(rs, og * slB + (R + qi) * NR + rl);
 #pragma unroll
-                    for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? cl_load(base + (size_t)gg * slB + 2 * R * NR + idx) : 0.f;
-                    fw_[jn] = cl_load(base + (size_t)og * slB + i * NR + rl);
-                    sCR[idx] = cl_load(base + (size_t)og * slB + (R + i) * NR + rl);
-                    float s = 0.f;
-#pragma unroll
-                    for (int gg = 0; gg < 8; ++gg) if (gg < k) s += pv[gg];
-                    bw_[jn] = s;
-                }
+                for (int gg = 0; gg < 8; ++gg) if (gg < k) bw_ += pv[gg];
             }
             __syncthreads();
             if (wave < R) mp_softmax_row(sCR + wave * N, N, lane);                      // read content weights
             __syncthreads();
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn) {
-                const int idx = tid + jn * CT;
-                if (jn < C.RNP && idx < R * N) {
-                    const int i = cl_div(idx, C.mg_N), n = idx - i * N;
-                    const float* rm = sI + C.oRm + i * 3;
-                    const float cr = sCR[idx];
-                    const float v = rm[2] * cr + rm[1] * fw_[jn] + rm[0] * bw_[jn];    // access.py:283-303 (num_writes = 1)
-                    sRW[idx] = v;
-                    if (rec && n >= row0 && n < row0 + NR) {
-                        a.rec_rw[bt * R * N + idx] = v;
-                        a.rec_cr[bt * R * N + idx] = cr;
-                        a.rec_fwd[bt * R * N + idx] = fw_[jn];
-                        a.rec_bwd[bt * R * N + idx] = bw_[jn];
-                    }
+            if (qok) {
+                const int idx = 4 * q4;
+                const float* rm = sI + C.oRm + qi * 3;
+                const f32x4 cr = *reinterpret_cast<const f32x4*>(sCR + idx);
+                const f32x4 v = rm[2] * cr + rm[1] * fw_ + rm[0] * bw_;                // access.py:283-303 (num_writes = 1)
+                *reinterpret_cast<f32x4*>(sRW + idx) = v;
+                if (rec && qn >= row0 && qn < row0 + NR) {
+                    *reinterpret_cast<f32x4*>(a.rec_rw + bt * R * N + idx) = v;
+                    *reinterpret_cast<f32x4*>(a.rec_cr + bt * R * N + idx) = cr;
+                    *reinterpret_cast<f32x4*>(a.rec_fwd + bt * R * N + idx) = fw_;
+                    *reinterpret_cast<f32x4*>(a.rec_bwd + bt * R * N + idx) = bw_;
                 }
             }
             const float sww = sSC[0];
@@ -650,15 +656,20 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
         if (!mp_wait(flC, epoch, k, a.err, a.sticky, sAbort, tid)) return;
         {
             const float* base = mbC + (size_t)par * k * slC;
-            for (int c = tid; c < RWd; c += CT) {
-                float pv[8];
+            const __amdgpu_buffer_rsrc_t rs = mp_rsrc(base, (size_t)k * slC);
+            for (int c4 = tid; c4 < (RWd >> 2); c4 += CT) {
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 pv[8];
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? cl_load(base + (size_t)gg * slC + c) : 0.f;
-                float s = 0.f;
+                for (int gg = 0; gg < 8; ++gg) pv[gg] = (gg < k) ? mp_load4(rs, gg * slC + 4 * c4) : z4;
+                f32x4 s = z4;
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) if (gg < k) s += pv[gg];
-                sZ[c] = s;
-                if (rec && g == 0) a.rec_yin[bt * C.ldy + hid + c] = s;
+                *reinterpret_cast<f32x4*>(sZ + 4 * c4) = s;
+                if (rec && g == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a.rec_yin[bt * C.ldy + hid + 4 * c4 + e] = s[e];
+                }
             }
             if (rec && g == 0 && tid < C.ldy - C.Ky) a.rec_yin[bt * C.ldy + C.Ky + tid] = (tid == 0) ? 1.f : 0.f;
         }
