@@ -204,9 +204,10 @@ DNC_FWD_TRAFFIC_BYTES_B32_S1300 = 4.56e9        # inference-mode forward (2 x FE
 DNC_BWD_TRAFFIC_BYTES_B32_S1300 = 2.123e10
 NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.950e9 + 0.162e9   # profiles/r02_ntm_seq_hbm_traffic_pmc.csv
 # HBM-side bytes per sequence-step of the memory-partitioned DNC cluster kernels at configs[4]'s shape (512 x 128, B 64):
-# profiles/r03_dnc_mp_hbm_traffic_pmc.csv (None until measured)
-DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = None
-DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP = None
+# profiles/r03_dnc_mp_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE over B 64 x S 200): the inference-mode forward moves
+# exactly the algorithmic bytes (2 650 112 per sequence-step); BPTT reads L_t, L_{t-1} and d(link) and rewrites d(link)
+DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = 2649848.0
+DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP = 5401708.0
 
 
 def _median_ms(fn, n=3):
