@@ -618,9 +618,11 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
                     const int r = r0 + u * RG;
                     gv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; ltv[u] = gv[u]; lpv[u] = gv[u];
                     if (r < NR && colok) {
-                        gv[u] = reinterpret_cast<const f32x4*>(gLg + (size_t)r * N)[c4];
-                        ltv[u] = reinterpret_cast<const f32x4*>(Ltg + (size_t)r * N)[c4];
-                        lpv[u] = reinterpret_cast<const f32x4*>(Lpg + (size_t)r * N)[c4];
+                        // non-temporal LOADS (read once: they should not push the weights out of L2; measured free in the probe,
+                        // non-temporal STORES cost 40 %: profiles/r03_link_stream_probe.txt)
+                        gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gLg + (size_t)r * N) + c4);
+                        ltv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ltg + (size_t)r * N) + c4);
+                        lpv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Lpg + (size_t)r * N) + c4);
                     }
                 }
 #pragma unroll

@@ -20,7 +20,7 @@ __device__ __forceinline__ f32x4 ld(const f32x4* p) { return NT ? __builtin_nont
 template <bool NT>
 __device__ __forceinline__ void st(f32x4* p, f32x4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 
-template <int MODE, int PF, bool NT>
+template <int MODE, int PF, bool NT, bool NTS = NT>
 __global__ __launch_bounds__(512) void link_stream(float* rec, float* gl, int steps, int N, int NR, int k, float* sink) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / k, g = blockIdx.x % k, B = gridDim.x / k;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void link_stream(float* rec, float* gl, int st
                         f32x4 x = (1.0f - wa - 1e-3f) * v[u][h] + wa;
                         colacc[h] += wa * x;
                         rowacc += x[0] + x[1] + x[2] + x[3];
-                        st<NT>(dst + (size_t)(r0 + u) * N4 + h * 64 + lane, x);
+                        st<NTS>(dst + (size_t)(r0 + u) * N4 + h * 64 + lane, x);
                     }
                 }
         }
@@ -69,22 +69,22 @@ __global__ __launch_bounds__(512) void link_stream(float* rec, float* gl, int st
     if (rowacc + colacc[0][0] + colacc[1][3] == 12345.678f) sink[0] = rowacc;
 }
 
-template <int MODE, int PF, bool NT>
+template <int MODE, int PF, bool NT, bool NTS = NT>
 static void run(float* rec, float* gl, float* sink, int B, int k, int steps, const char* name) {
     const int N = 512, NR = N / k;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    link_stream<MODE, PF, NT><<<B * k, 512>>>(rec, gl, 8, N, NR, k, sink);      // warm
+    link_stream<MODE, PF, NT, NTS><<<B * k, 512>>>(rec, gl, 8, N, NR, k, sink);      // warm
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    link_stream<MODE, PF, NT><<<B * k, 512>>>(rec, gl, steps, N, NR, k, sink);
+    link_stream<MODE, PF, NT, NTS><<<B * k, 512>>>(rec, gl, steps, N, NR, k, sink);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double per_step_bytes = (double)B * N * N * 4 * (MODE == 2 ? 4.0 : 2.0);
     const double us = ms * 1e3 / (steps - 1);
-    printf("%-34s B=%d k=%d PF=%d NT=%d: %8.2f us/step  %7.1f GB/s (%.0f MB per step)\n", name, B, k, PF, (int)NT, us,
+    printf("%-34s B=%d k=%d PF=%d NTload=%d NTstore=%d: %8.2f us/step  %7.1f GB/s (%.0f MB per step)\n", name, B, k, PF, (int)NT, (int)NTS, us,
            per_step_bytes / (us * 1e-6) / 1e9, per_step_bytes / 1e6);
     fflush(stdout);
 }
@@ -107,6 +107,10 @@ int main() {
     run<1, 4, true>(rec, gl, sink, B, 4, steps, "record stream");
     run<1, 8, false>(rec, gl, sink, B, 4, steps, "record stream");
     run<1, 8, true>(rec, gl, sink, B, 4, steps, "record stream");
+    run<1, 4, true, false>(rec, gl, sink, B, 4, steps, "record stream");
+    run<1, 4, false, true>(rec, gl, sink, B, 4, steps, "record stream");
+    run<0, 4, true, false>(rec, gl, sink, B, 4, steps, "ping-pong");
+    run<0, 4, false, true>(rec, gl, sink, B, 4, steps, "ping-pong");
     run<2, 2, false>(rec, gl, sink, B, 4, steps, "bptt (L_t, L_t-1, dL r/w)");
     run<2, 4, false>(rec, gl, sink, B, 4, steps, "bptt (L_t, L_t-1, dL r/w)");
     run<2, 4, true>(rec, gl, sink, B, 4, steps, "bptt (L_t, L_t-1, dL r/w)");
