@@ -307,6 +307,8 @@ int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int 
  * last launch or (sticky word) any launch since the word was last cleared aborted; clear_sticky != 0 clears it. */
 int ntk_cu_count(void);
 int ntk_dnc_mp_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes);
+/* > 0 when (shape, k) has a compile-time instantiation of the mp kernels (the generic one is functional but several times slower) */
+int ntk_dnc_mp_compiled_shape(int N, int W, int R, int Wn, int hid, int O, int k);
 int ntk_dnc_mp_status(const void* workspace, size_t workspace_bytes, int B, int k, int clear_sticky, void* stream);
 int ntk_dnc_mp_placement(const void* workspace, int B, int k, int* same_xcd_clusters, void* stream);
 int ntk_dnc_mp_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value, int k,

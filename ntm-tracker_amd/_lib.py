@@ -49,6 +49,7 @@ def _sig(lib):
         "ntk_dnc_cluster_bwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P, c_int, P, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P, c_int, P, P]),
         "ntk_cu_count": (c_int, []),
         "ntk_dnc_mp_plan": (c_int, [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
+        "ntk_dnc_mp_compiled_shape": (c_int, [c_int] * 7),
         "ntk_dnc_mp_status": (c_int, [P, c_size_t, c_int, c_int, c_int, P]),
         "ntk_dnc_mp_placement": (c_int, [P, c_int, c_int, P, P]),
         "ntk_dnc_mp_fwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P] * 13 + [P] * 18 + [P, P]),

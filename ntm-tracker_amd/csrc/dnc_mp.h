@@ -80,11 +80,23 @@ static constexpr __host__ __device__ DncMpCfg dnc_mp_cfg(int N, int W, int R, in
     return c;
 }
 
-// the shape the memory-partitioned form exists for: BASELINE configs[4]'s core (DNC 512 x 128, 4 read heads, hidden 200,
-// 2 outputs) at 4 workgroups per sequence (64 sequences = 256 workgroups = every CU)
-constexpr DncMpCfg kDncMpFixCfg = dnc_mp_cfg(512, 128, 4, 200, 2, 4);
-static inline bool dnc_mp_is_fix(const DncMpCfg& c) {
-    return c.N == 512 && c.W == 128 && c.R == 4 && c.hid == 200 && c.O == 2 && c.k == 4;
+// Shapes with a compile-time instantiation of the kernels (every dimension, offset and LDS address an immediate; the generic
+// instantiation reads them from the kernarg segment and its unrolled eight-row loops with run-time guards spill heavily):
+//   1  BASELINE configs[4]'s core: DNC 512 x 128, 4 read heads, hidden 200, 2 outputs, 4 workgroups per sequence
+//      (64 sequences = 256 workgroups = every CU) -- the shape this form exists for;
+//   2  BASELINE configs[2]'s core (256 x 64) at 4 workgroups per sequence: 32 sequences on HALF the chip, so that the trunk pass
+//      of the next batch runs on the other half at the same time (the LDS-resident form needs k = 8 = every CU);
+//   3  the same core at 8 workgroups per sequence.
+constexpr int MP_SHAPES = 3;
+static constexpr __host__ __device__ DncMpCfg dnc_mp_shape_cfg(int shape) {
+    return shape == 2 ? dnc_mp_cfg(256, 64, 4, 200, 2, 4) : (shape == 3 ? dnc_mp_cfg(256, 64, 4, 200, 2, 8) : dnc_mp_cfg(512, 128, 4, 200, 2, 4));
+}
+static inline int dnc_mp_shape_of(const DncMpCfg& c) {
+    for (int sh = 1; sh <= MP_SHAPES; ++sh) {
+        const DncMpCfg f = dnc_mp_shape_cfg(sh);
+        if (c.N == f.N && c.W == f.W && c.R == f.R && c.hid == f.hid && c.O == f.O && c.k == f.k) return sh;
+    }
+    return 0;
 }
 
 // control block of a launch: flags [B][MPX][k], the error word, the XCC words of the handshake [B][k]; padded to 256 bytes;

@@ -105,8 +105,6 @@ constexpr __host__ __device__ DncMpBwdLds dnc_mp_bwd_lds(const DncMpCfg& c, cons
     L.total = o;
     return L;
 }
-constexpr DncMpBwdGeo kDncMpFixBwdGeo = dnc_mp_bwd_geo(kDncMpFixCfg);
-constexpr DncMpBwdLds kDncMpFixBwdLds = dnc_mp_bwd_lds(kDncMpFixCfg, kDncMpFixBwdGeo);
 
 struct DncMpBwdArgs {
     int B, S, xcd_local, carry_in;
@@ -163,8 +161,12 @@ __device__ __forceinline__ f32x4 mpb_fold4(f32x4 v, int LPR) {
     (void)sRWp; (void)sRWt; (void)sgRW; (void)sG; (void)sDRWp; (void)sDSIM; (void)sSIMr; (void)sGZ; (void)sDR; (void)sDHC; (void)sDG;     \
     (void)sgC; (void)sAbort; (void)row0; (void)u0
 
-template <bool FIX>
+template <int SH>
 __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
+    constexpr bool FIX = SH != 0;
+    constexpr DncMpCfg kDncMpFixCfg = dnc_mp_shape_cfg(SH);
+    constexpr DncMpBwdGeo kDncMpFixBwdGeo = dnc_mp_bwd_geo(kDncMpFixCfg);
+    constexpr DncMpBwdLds kDncMpFixBwdLds = dnc_mp_bwd_lds(kDncMpFixCfg, kDncMpFixBwdGeo);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef const __attribute__((address_space(4))) DncMpBwdArgs* ArgsK;
     const ArgsK ak0 = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1192,19 +1194,25 @@ extern "C" int ntk_dnc_mp_bwd(int B, int S, int N, int W, int R, int Wn, int hid
     a.sticky = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + wsb - 256);
     {
         static NtkLdsAttrCache lds_cache;
-        const void* const ks[] = {(const void*)dnc_mp_bwd_kernel<false>, (const void*)dnc_mp_bwd_kernel<true>};
-        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 2, "ntk_dnc_mp_bwd");
+        const void* const ks[] = {(const void*)dnc_mp_bwd_kernel<0>, (const void*)dnc_mp_bwd_kernel<1>, (const void*)dnc_mp_bwd_kernel<2>,
+                                  (const void*)dnc_mp_bwd_kernel<3>};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 4, "ntk_dnc_mp_bwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
     hipError_t e = hipMemsetAsync(workspace, 0, ctrl, (hipStream_t)stream);
     NTK_REQUIRE(e == hipSuccess, NTK_ERR_HIP, "ntk_dnc_mp_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
 #ifdef NTK_DNC_MP_GENERIC
-    const bool use_fix = false;
+    const int shape = 0;
 #else
-    const bool use_fix = dnc_mp_is_fix(a.c);
+    const int shape = dnc_mp_shape_of(a.c);
 #endif
-    if (use_fix) dnc_mp_bwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
-    else dnc_mp_bwd_kernel<false><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
+    const dim3 grid(B * k);
+    switch (shape) {
+        case 1: dnc_mp_bwd_kernel<1><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+        case 2: dnc_mp_bwd_kernel<2><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+        case 3: dnc_mp_bwd_kernel<3><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+        default: dnc_mp_bwd_kernel<0><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+    }
     NTK_CHECK_LAUNCH("ntk_dnc_mp_bwd");
     return NTK_OK;
 }

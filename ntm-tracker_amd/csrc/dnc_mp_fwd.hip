@@ -67,7 +67,6 @@ constexpr __host__ __device__ DncMpFwdLds dnc_mp_fwd_lds(const DncMpCfg& c) {
     L.total = o;
     return L;
 }
-constexpr DncMpFwdLds kDncMpFixFwdLds = dnc_mp_fwd_lds(kDncMpFixCfg);
 
 struct DncMpFwdArgs {
     int B, S, xcd_local;
@@ -117,8 +116,11 @@ constexpr int MP_PFL = 4;     // link rows a wave keeps in flight
     (void)sKEY; (void)sRank; (void)sNU; (void)sCW; (void)sCR; (void)sK; (void)sAbort; (void)sM; (void)sI; (void)sC; (void)sHP; (void)k; \
     (void)sM4; (void)sU; (void)sP; (void)sWW; (void)sRW; (void)row0
 
-template <bool FIX>
+template <int SH>
 __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
+    constexpr bool FIX = SH != 0;
+    constexpr DncMpCfg kDncMpFixCfg = dnc_mp_shape_cfg(SH);
+    constexpr DncMpFwdLds kDncMpFixFwdLds = dnc_mp_fwd_lds(kDncMpFixCfg);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef const __attribute__((address_space(4))) DncMpFwdArgs* ArgsK;
     const ArgsK ak0 = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -779,6 +781,14 @@ extern "C" int ntk_dnc_mp_plan(int B, int N, int W, int R, int Wn, int hid, int 
     return NTK_OK;
 }
 
+// > 0 when the shape has a compile-time instantiation of the mp kernels (csrc/dnc_mp.h: the generic instantiation is several
+// times slower), 0 otherwise
+extern "C" int ntk_dnc_mp_compiled_shape(int N, int W, int R, int Wn, int hid, int O, int k) {
+    if (Wn != 1 || k < 1 || N < 1 || (N % k) != 0) return 0;
+    const DncMpCfg c = dnc_mp_cfg(N, W, R, hid, O, k);
+    return dnc_mp_shape_of(c);
+}
+
 extern "C" int ntk_dnc_mp_status(const void* workspace, size_t workspace_bytes, int B, int k, int clear_sticky, void* stream) {
     NTK_REQUIRE(workspace && B > 0 && k > 0 && workspace_bytes >= dnc_mp_ctrl_bytes(B, k) + 256, NTK_ERR_BAD_PTR, "ntk_dnc_mp_status: bad arguments");
     unsigned e[2] = {0, 0};
@@ -855,19 +865,25 @@ extern "C" int ntk_dnc_mp_fwd(int B, int S, int N, int W, int R, int Wn, int hid
     a.sticky = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + wsb - 256);
     {
         static NtkLdsAttrCache lds_cache;
-        const void* const ks[] = {(const void*)dnc_mp_fwd_kernel<false>, (const void*)dnc_mp_fwd_kernel<true>};
-        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 2, "ntk_dnc_mp_fwd");
+        const void* const ks[] = {(const void*)dnc_mp_fwd_kernel<0>, (const void*)dnc_mp_fwd_kernel<1>, (const void*)dnc_mp_fwd_kernel<2>,
+                                  (const void*)dnc_mp_fwd_kernel<3>};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 4, "ntk_dnc_mp_fwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
     hipError_t e = hipMemsetAsync(workspace, 0, ctrl, (hipStream_t)stream);     // flags + error word: zero before EVERY launch
     NTK_REQUIRE(e == hipSuccess, NTK_ERR_HIP, "ntk_dnc_mp_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
 #ifdef NTK_DNC_MP_GENERIC
-    const bool use_fix = false;
+    const int shape = 0;
 #else
-    const bool use_fix = dnc_mp_is_fix(a.c);
+    const int shape = dnc_mp_shape_of(a.c);
 #endif
-    if (use_fix) dnc_mp_fwd_kernel<true><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
-    else dnc_mp_fwd_kernel<false><<<B * k, CT, lds_bytes, (hipStream_t)stream>>>(a);
+    const dim3 grid(B * k);
+    switch (shape) {
+        case 1: dnc_mp_fwd_kernel<1><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+        case 2: dnc_mp_fwd_kernel<2><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+        case 3: dnc_mp_fwd_kernel<3><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+        default: dnc_mp_fwd_kernel<0><<<grid, CT, lds_bytes, (hipStream_t)stream>>>(a); break;
+    }
     NTK_CHECK_LAUNCH("ntk_dnc_mp_fwd");
     return NTK_OK;
 }

@@ -127,8 +127,11 @@ def test_config5_shape_dnc_training_step_properties(cuda):
     assert float(loss_2.cpu()) < float(loss_f.cpu())
 
 
-def test_config3_fullsize_dnc_training_step_properties(cuda):
-    """BASELINE config 3 at full size (DNC 256x64, 4 read heads; 32 sequences x 20 frames -> 1300 strictly sequential
+@pytest.mark.parametrize("form,k", [("lds", 8), ("mp", 4)], ids=["lds_k8_whole_chip", "mp_k4_half_chip"])
+def test_config3_fullsize_dnc_training_step_properties(cuda, form, k):
+    """(Both cluster forms: the LDS-resident one at 8 workgroups per sequence = every CU, and the memory-partitioned one at 4 =
+    half the chip, which is what DNCOffsetTracker picks when it has a trunk to run beside the core.)
+    BASELINE config 3 at full size (DNC 256x64, 4 read heads; 32 sequences x 20 frames -> 1300 strictly sequential
     steps, every CU of the chip in an 8-workgroup cluster per sequence): the whole training step (recorded forward,
     loss, BPTT, weight-gradient GEMMs) is finite, bitwise reproducible run to run (fixed-order reductions and
     hand-offs: no float atomics on the cluster path), no hand-off times out, and duplicating a half batch doubles the
@@ -141,16 +144,18 @@ def test_config3_fullsize_dnc_training_step_properties(cuda):
     offs_h = (torch.rand((B // 2, T, 2), generator=g) - 0.5).to(cuda)
     kw = dict(vgg_weights=None, mem_size=256, mem_dim=64, device=cuda, seed=6)
     half = tracker.DNCOffsetTracker(B // 2, T, **kw)
+    half.core.cluster_form, half.core.cluster_k = form, k
     loss_h, _ = half.loss_and_grads(fmap_h, gts_h, offs_h)
     half.core.check_cluster()
-    assert half.core.last_cluster_k == 8 and half.core.last_cluster_bwd_k == 8
+    assert half.core.last_cluster_k == k and half.core.last_cluster_bwd_k == k and half.core.last_cluster_form == form
     args = (torch.cat([fmap_h, fmap_h]), torch.cat([gts_h, gts_h]), torch.cat([offs_h, offs_h]))
     grads = []
     for _ in range(2):
         full = tracker.DNCOffsetTracker(B, T, **kw)
+        full.core.cluster_form, full.core.cluster_k = form, k
         loss_f, _ = full.loss_and_grads(*args)
         full.core.check_cluster()
-        assert full.core.last_cluster_k == 8 and full.core.last_cluster_bwd_k == 8
+        assert full.core.last_cluster_k == k and full.core.last_cluster_bwd_k == k and full.core.last_cluster_bwd_form == form
         grads.append(full.core.params.grad.clone())
     torch.cuda.synchronize()
     assert torch.equal(grads[0], grads[1]), "the DNC training step is not bitwise reproducible"
