@@ -18,7 +18,7 @@
 // 1 KB payloads): 4.8 us per exchange across XCDs, 3.5 us with write-through stores on one XCD, 1.9 us with plain stores.
 // A cluster that spans XCDs (or a launch whose batch is not a multiple of 8) keeps the write-through form.
 // Epochs are step + 1, flags are zeroed by a memset node ahead of every launch, payload slots are double-buffered by
-// step parity.  Every spin is bounded (s_memrealtime, ~3 s): on timeout the waiter raises the launch's error word,
+// step parity.  Every spin is bounded (s_memrealtime, ~3 s from the start of THAT wait): on timeout the waiter raises the launch's error word,
 // which every other spin also watches, and all workgroups leave the kernel (outputs are then garbage and the host
 // reports NTK_ERR_HIP from ntk_dnc_cluster_status).  All k * B workgroups must be co-resident: the host caps the
 // grid at one workgroup per CU.
@@ -94,14 +94,17 @@ __device__ __forceinline__ int cl_same_xcd(unsigned* xw, int g, int k, unsigned*
 // launch was aborted.  s_abort: one int in LDS, zero-initialised before the first call.
 __device__ __forceinline__ bool cl_wait(const unsigned* flags, unsigned epoch, int k, unsigned* err, int* s_abort,
                                         unsigned long long t_start, int tid) {
+    (void)t_start;      // the bound is on ONE stalled exchange, not on the kernel's run time: the time base is taken inside the wait
     if (tid < 64) {
         unsigned spins = 0;
+        unsigned long long t0 = 0;
         for (;;) {
             const unsigned v = (tid < k) ? __hip_atomic_load(flags + tid, NTK_RLX, NTK_AGENT) : epoch;
             if (__all((int)(v - epoch) >= 0)) break;
             if ((++spins & 127u) == 0) {
-                const bool dead = __hip_atomic_load(err, NTK_RLX, NTK_AGENT) != 0 ||
-                                  (__builtin_amdgcn_s_memrealtime() - t_start) > 300000000ull;      // 3 s at 100 MHz
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                const bool dead = __hip_atomic_load(err, NTK_RLX, NTK_AGENT) != 0 || (now - t0) > 300000000ull;      // 3 s at 100 MHz
                 if (dead) {
                     if (tid == 0) { __hip_atomic_store(err, 1u, NTK_RLX, NTK_AGENT); *s_abort = 1; }
                     break;

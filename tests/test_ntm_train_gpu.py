@@ -88,9 +88,17 @@ def test_bptt_gradients_match_autograd_oracle(cuda, name, kw, D, T, B, scale):
     np.testing.assert_allclose(logits.cpu().numpy(), logits_ref, atol=2e-5)
     np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-4)
     got = cell.params.to_tf(grad=True)
+    # bound per tensor, relative to its largest entry: 1e-4 -- or, where the float32 evaluation of the SAME restatement is
+    # itself further than that from float64 (sums with heavy cancellation), no further from float64 than 3x what it is
+    _l32, grads32, _lg32, _p32 = OT.loss_and_grads(cfg, params, x, offs, dtype=torch.float32)
+    worst, bad = {}, {}
     for k in sorted(grads_ref):
-        err = _relerr(got[k].numpy(), grads_ref[k])
-        assert err < 2e-3, "%s: relative error %.3e" % (k, err)
+        err, err32 = _relerr(got[k].numpy(), grads_ref[k]), _relerr(grads32[k].astype(np.float64), grads_ref[k])
+        worst[k] = (err, err32)
+        if err > max(1e-4, 3 * err32):
+            bad[k] = (err, err32)
+    print("%s relative gradient error (HIP, float32 oracle) vs float64: %s" % (name, {k: ("%.1e" % a, "%.1e" % b_) for k, (a, b_) in worst.items()}))
+    assert not bad, bad
 
 
 def test_train_step_matches_oracle_update(cuda):
