@@ -36,7 +36,6 @@ __device__ unsigned long long g_mpb_prof[32];
 namespace {
 
 constexpr int MPQ = 8;        // memory rows per lane group (own rows <= 8 * 512 / LPR)
-constexpr int MPB_PFL = 2;    // link rows a wave keeps in flight (three streams per row)
 
 struct DncMpBwdGeo {
     int ldkT, ldhT, kg4;
@@ -167,6 +166,9 @@ __global__ __launch_bounds__(CT) void dnc_mp_bwd_kernel(DncMpBwdArgs a0) {
     constexpr DncMpCfg kDncMpFixCfg = dnc_mp_shape_cfg(SH);
     constexpr DncMpBwdGeo kDncMpFixBwdGeo = dnc_mp_bwd_geo(kDncMpFixCfg);
     constexpr DncMpBwdLds kDncMpFixBwdLds = dnc_mp_bwd_lds(kDncMpFixCfg, kDncMpFixBwdGeo);
+    // link rows a wave keeps in flight (three streams per row): 2 at 512 columns (bandwidth bound), 4 where the pass is a few
+    // rows per wave and latency bound (256 columns)
+    constexpr int MPB_PFL = (FIX && kDncMpFixCfg.NH == 1) ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef const __attribute__((address_space(4))) DncMpBwdArgs* ArgsK;
     const ArgsK ak0 = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();

@@ -95,7 +95,6 @@ __device__ __forceinline__ float mp_dot4(const f32x4& x, const f32x4& y) { retur
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int MP_PFL = 4;     // link rows a wave keeps in flight
 
 #define MP_FWD_VIEWS()                                                                                                        \
     const int k = C.k, NR = C.NR, upk = C.upk, upkp = C.upkp;                                                                 \
@@ -121,6 +120,9 @@ __global__ __launch_bounds__(CT) void dnc_mp_fwd_kernel(DncMpFwdArgs a0) {
     constexpr bool FIX = SH != 0;
     constexpr DncMpCfg kDncMpFixCfg = dnc_mp_shape_cfg(SH);
     constexpr DncMpFwdLds kDncMpFixFwdLds = dnc_mp_fwd_lds(kDncMpFixCfg);
+    // link rows a wave keeps in flight: 4 rows of two float4 per lane (512 columns: the pass is bandwidth bound), 8 rows of one
+    // float4 where a row fits one 256-column half (256 x 64 at k = 4: a wave owns 8 rows, two batches were two HBM round trips)
+    constexpr int MP_PFL = (FIX && kDncMpFixCfg.NH == 1) ? 8 : 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef const __attribute__((address_space(4))) DncMpFwdArgs* ArgsK;
     const ArgsK ak0 = (ArgsK)__builtin_amdgcn_kernarg_segment_ptr();

@@ -306,7 +306,7 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         # Which cluster form, and does the trunk run beside it?  A cooperative core over every CU takes the chip alone
         # (serial_trunk).  Where the memory-partitioned form has a compile-time instantiation at a cluster size that leaves
         # HALF the chip free (2 B k <= CUs), that form runs instead and the trunk pass of the next batch overlaps it on the
-        # other half: BASELINE configs[2] (256 x 64, B 32) at k = 4 on 128 CUs: 124.1 -> 111.5 ms per step, although the core
+        # other half: BASELINE configs[2] (256 x 64, B 32) at k = 4 on 128 CUs: 124.1 -> 107.3 ms per step, although the core
         # alone is slower there (89 ms on half the chip vs 69 ms on all of it).
         L, c = _lib.lib(), self.core
         if self.vgg is not None and c.cluster_form is None and c.cluster_k is None and not os.environ.get("NTK_DNC_CLUSTER_FORM") \
@@ -314,6 +314,10 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
             for k in (2, 4):
                 if 2 * self.B * k <= L.ntk_cu_count() and L.ntk_dnc_mp_compiled_shape(c.N, c.W, c.R, c.Wn, c.hid, c.O, k) > 0:
                     c.cluster_form, c.cluster_k = "mp", k
+                    # on half a chip the trunk's two half-batch streams only fight each other: one stream
+                    # (configs[2]: 111.4 -> 107.3 ms per step; four parts: 113.6)
+                    if not os.environ.get("NTK_TRUNK_SPLIT"):
+                        self.vgg.split_streams = 1
         if os.environ.get("NTK_DNC_SERIAL_TRUNK"):
             self.serial_trunk = os.environ["NTK_DNC_SERIAL_TRUNK"] != "0"
         else:
