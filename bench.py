@@ -259,7 +259,7 @@ def memory_step_probe(trk, model, gts0, offs, B, T):
         kern = (fam[form] % "fwd" + " (k = %d workgroups per sequence)" % k) if k > 1 else "dnc_seq_fwd_kernel"
         kern_b = ((fam[form_b] % "bwd" + " (k = %d)" % kb) if kb > 1 else "dnc_seq_bwd_kernel") + " (+ 4 weight-gradient GEMMs)"
         if getattr(c, "last_segments", None):
-            kern_b += "; %d BPTT segments: this time includes re-recording all but the last with the forward kernel" % len(c.last_segments[1])
+            kern_b += "; %d BPTT segments: this time includes re-recording all but the last two (recorded by the forward pass) with the forward kernel" % len(c.last_segments[1])
         is_c3 = (c.N, c.W, c.R) == (256, 64, 4) and form == "lds"
         is_c5 = (c.N, c.W, c.R) == (512, 128, 4) and form == "mp"
         traffic = DNC_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else (
@@ -413,7 +413,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    log("timed %d steps in %.3f s" % (args.steps, elapsed))
+    log("timed %d steps in %.3f s; peak device memory allocated %.1f GB, reserved %.1f GB" % (
+        args.steps, elapsed, torch.cuda.max_memory_allocated(dev) / 1e9, torch.cuda.max_memory_reserved(dev) / 1e9))
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -281,6 +281,8 @@ class DNC(object):
     bptt_segment = None
     last_record = None
     last_segments = None
+    #: how many trailing segments the forward pass of a segmented run records itself (2 = as many as may be alive at a time)
+    recorded_tail_segments = 2
     _rerec_stream = None
     last_initial = None
 
@@ -440,18 +442,23 @@ class DNC(object):
         xp = xproj.view(B, S, 4 * self.hid)
         out = torch.empty((B, S, self.O), device=self.device)
         ckpt, bounds = [], []
-        last_rec = {}
-        for s0 in range(0, S, seg):
+        starts = list(range(0, S, seg))
+        # The LAST TWO segments are recorded right here: BPTT walks the segments last to first and two record sets may be
+        # alive at a time (record_budget_bytes), so neither of them needs a second forward pass -- the forward work of a
+        # training step is S + (n - 2) / n * S steps instead of S + (n - 1) / n * S (three segments at config 5: 1.33 S, not 1.67 S)
+        keep_from = max(0, len(starts) - self.recorded_tail_segments)
+        recs = {}
+        for si, s0 in enumerate(starts):
             s1 = min(S, s0 + seg)
             ckpt.append(st)
             bounds.append((s0, s1))
-            # the LAST segment is recorded right here: BPTT starts with it, so it never needs a second forward pass
-            rec = self._alloc_records(B, s1 - s0, cap=seg) if s1 == S else {}
+            rec = self._alloc_records(B, s1 - s0, cap=seg) if si >= keep_from else {}
             o, st = self._launch_fwd(xp[:, s0:s1].contiguous().view(B * (s1 - s0), 4 * self.hid), B, s1 - s0, st, rec)
             out[:, s0:s1] = o
-            last_rec = rec
+            if rec:
+                recs[si] = rec
         self.last_record = {}
-        self.last_segments = (xp, ckpt, bounds, last_rec, seg)
+        self.last_segments = (xp, ckpt, bounds, recs, seg)
         return out.transpose(0, 1), self._strip_state(st)
 
     def _launch_bwd(self, B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, gcarry, carry_in):
@@ -519,7 +526,8 @@ class DNC(object):
             dgates, dxi, dypre = self._launch_bwd(B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, None, False)
             self._weight_grads(X.view(B * S, self.ldx), rec, dgates, dxi, dypre, B * S, False)
             return self._unpack(grad=True)
-        xp, ckpt, bounds, last_rec, seg_cap = self.last_segments
+        xp, ckpt, bounds, fwd_recs, seg_cap = self.last_segments
+        nseg = len(bounds)
         gcarry = torch.zeros((B, (self.Wn + 1) * self.N + self.R * self.N + ldkT + hid), device=dev)
         # Last segment first.  The re-recording forward pass of segment s - 1 depends only on its checkpoint, so it runs on a
         # side stream (other CUs: these kernels hold one CU per sequence) WHILE segment s is back-propagated: the second forward
@@ -532,6 +540,9 @@ class DNC(object):
         segs = list(zip(reversed(ckpt), reversed(bounds)))
 
         def rerecord(k):
+            si = nseg - 1 - k                                      # segs is last-to-first
+            if si in fwd_recs:                                     # recorded by the forward pass itself: consumed here
+                return fwd_recs.pop(si), None                      # (no second reference: the set must die with its segment)
             st_k, (a0, a1) = segs[k]
             # records come from THIS stream's allocator pool (a freed set is reused two segments later; pools are per stream:
             # allocating on the side stream kept three sets alive and ran out of HBM at config 5); the side stream orders
@@ -547,12 +558,7 @@ class DNC(object):
                 ev.record(side)
             return r, ev
 
-        if last_rec:
-            pending = (last_rec, None)                             # recorded by the forward pass itself
-            last_rec = None                                        # (no second reference: the set must die with its segment)
-            self.last_segments = (xp, ckpt, bounds, None, seg_cap)     # consumed: a second backward call re-records it
-        else:
-            pending = rerecord(0)
+        pending = rerecord(0)
         first = True
         for k, (st, (s0, s1)) in enumerate(segs):
             n = s1 - s0
