@@ -298,7 +298,6 @@ __global__ __launch_bounds__(CT) void dnc_cluster_bwd_kernel(DncClBwdArgs a0) {
         const int par = t & 1;
         const float* Ltg = a.rec_L + (bt * N + row0) * N;
         const float* Lpg = (t > 0) ? a.rec_L + ((bt - 1) * N + row0) * N : a.link0 + ((size_t)b * N + row0) * N;
-        const float* gRWt = a.rec_rw + bt * RN;          // single-use records are read where they are consumed
 
         CLB_STAMP(0);
         // ------------------------------------------------------------ this step's records: registers -> LDS; next step's requested
