@@ -79,3 +79,45 @@ def test_geometry_known_answers_of_the_reference():
     assert G.offset_bbox((.1, .2, .3, .4), (.5, -.1)) == (.6, .1, .8, .30000000000000004)
     assert G.generate_gt([.25, .25, .75, .75], 8, 6, 4).shape == (8, 8)      # sigma = 6 // 4 = 1 (Python-2 division)
     np.testing.assert_allclose(G.generate_gt([.25, .25, .75, .75], 8, 6, 4), G.discrete_gauss((.5, .5), (8, 8), 1))
+
+
+def test_bench_synthetic_inputs_follow_the_shard_ranges():
+    """Rank r of a data-parallel bench run generates exactly the sequences parallel.shard_range gives it: the union over
+    ranks is what a single process holds (bench.py)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    from ntmtrack import parallel
+    GB, T, world = 4, 2, 2
+    whole = bench.synth_inputs(GB, T, "cpu", 42)
+    for r in range(world):
+        lo, hi = parallel.shard_range(GB, r, world)
+        part = bench.synth_inputs(hi - lo, T, "cpu", 42, first_sequence=lo)
+        assert torch.equal(part[0], whole[0][lo * T:hi * T]) and torch.equal(part[2], whole[2][lo:hi])
+        assert torch.equal(part[1], whole[1][lo:hi])
+    assert float(whole[2][:, 0].abs().max()) == 0.0               # frame 0 carries no offset (direct_offset_output.py:581-606)
+    q = bench._cgroup_cpu_quota()
+    assert q is None or q > 0
+
+
+def test_dnc_segment_plan_is_even_and_records_two_tail_segments():
+    """Segmented BPTT (config 5): the segment length is the even split of the smallest segment count the record budget
+    allows, so a record set is no larger than it has to be (the allocator's reserved peak fell from 300 to 205 GB)."""
+    from ntmtrack.dnc import DNC
+    core = object.__new__(DNC)                                    # host arithmetic only: no device, no library
+    core.N, core.W, core.R, core.Wn, core.hid, core.O = 512, 128, 4, 1, 200, 2
+    core.ldz, core.ldh, core.ldy, core.IP = 716, 204, 716, 920
+    core.bptt_segment = None
+    per_step = 4 * 64 * core._record_floats_per_step()
+    assert 86e6 < per_step < 88e6                                 # 1.36 MB per sequence-step x 64 sequences
+    seg = core._segment_len(64, 3250)
+    assert seg == 1084 and -(-3250 // seg) == 3 and seg * per_step <= DNC.record_budget_bytes
+    assert core._segment_len(32, 3250) == 1625                    # half the batch: two segments
+    assert core._segment_len(32, 1300) == 1300                    # config 3's shape fits whole
+    core.bptt_segment = 50
+    assert core._segment_len(4, 195) == 50
+    assert DNC.recorded_tail_segments == 2
