@@ -746,8 +746,11 @@ static int dnc_mp_pick(int B, int N, int W, int R, int Wn, int hid, int O, int k
         hid > 1024 || O < 1 || O > CW - 1 || B < 1)
         return 0;
     const int cus = ntk_device_cu_count();
+    // k_req 0: first the cluster sizes whose shape has a compile-time instantiation (several times faster), then any
+    for (int pass = 0; pass < 2; ++pass)
     for (int k = 2; k <= 8; k <<= 1) {
         if (k_req > 0 && k != k_req) continue;
+        if (pass == 0 && (k_req > 0 ? false : dnc_mp_shape_of(dnc_mp_cfg(N, W, R, hid, O, k)) == 0)) continue;
         if ((long)B * k > cus) continue;                       // one workgroup per CU, all co-resident
         const int NR = N / k;
         if (NR * k != N || NR < 8 || (NR % 8) != 0) continue;
