@@ -607,6 +607,7 @@ namespace {
 // resident in registers for the whole kernel, and waves stride over the row segments of the batch.
 // Same arithmetic as the tile kernel: a k-ordered fp32 MFMA chain over k = tap * 3 + c.
 // ---------------------------------------------------------------------------
+template <bool OUTBF16>        // OUTBF16: conv1_1 of the bf16 trunk (config 5): the same fp32 arithmetic, rounded once on store
 __global__ __launch_bounds__(256, 4) void conv_c3_rows_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int nseg, int H, int W) {
@@ -647,12 +648,20 @@ __global__ __launch_bounds__(256, 4) void conv_c3_rows_kernel(const float* __res
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b0[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b1[s], acc1, 0, 0, 0);
         }
-        float* orow = out + ((size_t)t * W + xs * 32) * 64;
+        const size_t o0 = ((size_t)t * W + xs * 32) * 64;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int mm = 4 * kh + (r & 3) + 8 * (r >> 2);
-            orow[(size_t)mm * 64 + m] = fmaxf(acc0[r] + bv0, 0.f);
-            orow[(size_t)mm * 64 + 32 + m] = fmaxf(acc1[r] + bv1, 0.f);
+            const float v0 = fmaxf(acc0[r] + bv0, 0.f), v1 = fmaxf(acc1[r] + bv1, 0.f);
+            if constexpr (OUTBF16) {
+                __bf16* orow = reinterpret_cast<__bf16*>(out) + o0;
+                orow[(size_t)mm * 64 + m] = (__bf16)v0;
+                orow[(size_t)mm * 64 + 32 + m] = (__bf16)v1;
+            } else {
+                float* orow = out + o0;
+                orow[(size_t)mm * 64 + m] = v0;
+                orow[(size_t)mm * 64 + 32 + m] = v1;
+            }
         }
     }
 }
@@ -684,7 +693,7 @@ extern "C" int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, 
         const long nseg = (long)frames * H * (W / 32);
         NTK_REQUIRE(nseg < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32: %ld row segments", nseg);
         const int wgs = (int)((nseg + 3) / 4 < 1024 ? (nseg + 3) / 4 : 1024);      // 256 CUs x 4 workgroups, waves stride over segments
-        conv_c3_rows_kernel<<<wgs, 256, 0, st>>>(in, w_packed, bias, out, (int)nseg, H, W);
+        conv_c3_rows_kernel<false><<<wgs, 256, 0, st>>>(in, w_packed, bias, out, (int)nseg, H, W);
     } else if (smallc) {
         if (bn128) launch_conv<128, true>(in, w_packed, bias, out, npatch, H, W, cin, cout, Kp, fuse_pool, st);
         else launch_conv<64, true>(in, w_packed, bias, out, npatch, H, W, cin, cout, Kp, fuse_pool, st);
@@ -707,6 +716,14 @@ extern "C" int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_
     const long npatch_l = (long)frames * (H / 4) * (W / 4);
     NTK_REQUIRE(npatch_l * 16 < 2147483647L - BM, NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32_to_bf16: too many pixels");
     const int npatch = (int)npatch_l;
+    if (cin == 3 && (W % 32) == 0) {            // the row kernel (4.06 -> store-bound at half the bytes: bit-identical results)
+        const long nseg = (long)frames * H * (W / 32);
+        NTK_REQUIRE(nseg < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32_to_bf16: %ld row segments", nseg);
+        const int wgs = (int)((nseg + 3) / 4 < 1024 ? (nseg + 3) / 4 : 1024);
+        conv_c3_rows_kernel<true><<<wgs, 256, 0, (hipStream_t)stream>>>(in, w_packed, bias, reinterpret_cast<float*>(out_bf16), (int)nseg, H, W);
+        NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_f32_to_bf16");
+        return NTK_OK;
+    }
     const long rtiles = (npatch_l * 16 + BM - 1) / BM;
     dim3 grid((unsigned)(((rtiles + 7) / 8) * 8));
     conv3x3_relu_kernel<64, true, false, true><<<grid, 256, 0, (hipStream_t)stream>>>(
