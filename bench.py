@@ -208,6 +208,10 @@ NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.950e9 + 0.162e9   # profiles/r02_ntm_seq_hbm
 # exactly the algorithmic bytes (2 650 112 per sequence-step); BPTT reads L_t, L_{t-1} and d(link) and rewrites d(link)
 DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = 2649848.0
 DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP = 5401708.0
+# ... and at configs[2]'s shape (256 x 64, B 32, k = 4; same file, second block): the inference forward's 8 MB of link state
+# stays in L2 / Infinity Cache, so fewer bytes than the algorithmic 669 696 reach HBM
+DNC_MP_C3_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = 311360.0
+DNC_MP_C3_BWD_TRAFFIC_BYTES_PER_SEQ_STEP = 1254740.0
 
 
 def _median_ms(fn, n=3):
@@ -262,15 +266,16 @@ def memory_step_probe(trk, model, gts0, offs, B, T):
             kern_b += "; %d BPTT segments: this time includes re-recording all but the last two (recorded by the forward pass) with the forward kernel" % len(c.last_segments[1])
         is_c3 = (c.N, c.W, c.R) == (256, 64, 4) and form == "lds"
         is_c5 = (c.N, c.W, c.R) == (512, 128, 4) and form == "mp"
+        is_c3mp = (c.N, c.W, c.R) == (256, 64, 4) and form == "mp" and k == 4
         traffic = DNC_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else (
-            DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if (is_c5 and DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP) else None)
+            DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if is_c5 else (DNC_MP_C3_FWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if is_c3mp else None))
         traffic_b = DNC_BWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0) if is_c3 else (
-            DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if (is_c5 and DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP) else None)
+            DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if is_c5 else (DNC_MP_C3_BWD_TRAFFIC_BYTES_PER_SEQ_STEP * B * S if is_c3mp else None))
         note = {"lds": "serialise + input projection + persistent cluster kernel: link rows and memory LDS resident, two mailbox hand-offs per step",
                 "mp": "serialise + input projection + persistent memory-partitioned cluster kernel: the link streams through HBM once per step "
                       "(N/k rows per workgroup), memory rows LDS resident, four mailbox hand-offs per step; HBM-bound link pass",
                 None: "serialise + input projection + persistent sequence kernel, one workgroup per sequence; link and memory L2 resident"}[form]
-        tnote = ("PMC, profiles/r03_dnc_mp_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE), inference-mode forward / BPTT kernel alone" if is_c5
+        tnote = ("PMC, profiles/r03_dnc_mp_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE), inference-mode forward / BPTT kernel alone" if (is_c5 or is_c3mp)
                  else "PMC, profiles/r02_dnc_cluster_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE)")
         if k > 1:
             pl = c.cluster_placement()

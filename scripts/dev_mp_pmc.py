@@ -5,9 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ntmtrack import dnc as G
 dev = torch.device("cuda:0")
-N, W, B, S = 512, 128, 64, int(sys.argv[1]) if len(sys.argv) > 1 else 200
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+N, W, B, K = [int(v) for v in (sys.argv[2:6] + ["512", "128", "64", "4"][len(sys.argv[2:6]):])]
 x = (torch.randn((S, B, 514), generator=torch.Generator().manual_seed(0)) * 0.5).to(dev)
 core = G.DNC({"memory_size": N, "word_size": W, "num_reads": 4, "num_writes": 1}, {"hidden_size": 200}, 2, 20.0, input_dim=514, device=dev, seed=1)
+core.cluster_form, core.cluster_k = "mp", K
 dout = torch.randn((B, S, 2), device=dev)
 for _ in range(2):
     core.run_sequence(x, record=False)
