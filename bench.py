@@ -205,9 +205,10 @@ DNC_BWD_TRAFFIC_BYTES_B32_S1300 = 2.123e10
 NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.950e9 + 0.162e9   # profiles/r02_ntm_seq_hbm_traffic_pmc.csv
 # HBM-side bytes per sequence-step of the memory-partitioned DNC cluster kernels at configs[4]'s shape (512 x 128, B 64):
 # profiles/r03_dnc_mp_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE over B 64 x S 200): the inference-mode forward moves
-# exactly the algorithmic bytes (2 650 112 per sequence-step); BPTT reads L_t, L_{t-1} and d(link) and rewrites d(link)
-DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = 2649848.0
-DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP = 5401708.0
+# 1.00 - 1.04x the algorithmic bytes (2 650 112 per sequence-step; two collections: 2 649 848 and 2 758 376 -- write-backs
+# straddle kernel boundaries); BPTT reads L_t, L_{t-1} and d(link) and rewrites d(link)
+DNC_MP_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = 2758376.0
+DNC_MP_BWD_TRAFFIC_BYTES_PER_SEQ_STEP = 5401689.0
 # ... and at configs[2]'s shape (256 x 64, B 32, k = 4; same file, second block): the inference forward's 8 MB of link state
 # stays in L2 / Infinity Cache, so fewer bytes than the algorithmic 669 696 reach HBM
 DNC_MP_C3_FWD_TRAFFIC_BYTES_PER_SEQ_STEP = 311360.0
