@@ -24,6 +24,7 @@
 //     A^T M A, bias, ReLU (+ 2x2 pool inside the 4x4 tile) and store one float4 per pixel, NHWC.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 // Diagnostic build only (make prof, -DNTK_CL_PROF): lane 0 of every wave of ONE workgroup accumulates s_memtime deltas per
 // section of the K loop into g_w43_prof[wave][section]; ntk_vgg_wino43_prof() copies them out (read SHARES, not totals).
@@ -548,11 +549,457 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same block (32 tiles x 64 output channels x 36 planes) on EIGHT waves, two per SIMD, 256 registers each.
+//
+// With one wave per SIMD every wait of that wave (LDS latency of the A / window reads, the U loads, the barrier) is an idle
+// matrix pipe.  Here a SIMD's nine planes x two 32-channel halves = 18 accumulator units are split UNEVENLY between its two
+// waves, and the rest of the work the other way round:
+//   waves 0..3 ("T"): 6 units (24 MFMAs per K step); the patch staging (global -> registers -> LDS) and the input transform of
+//                     the next K step (task = wave: plane rows (1,2), (3,4), 0, 5), done FIRST in a K step;
+//   waves 4..7 ("S"): 12 units (48 MFMAs per K step) and nothing else: the matrix pipe has their work while the T wave of the
+//                     same SIMD waits for its window reads and runs its row / column passes.
+// (An even 9 / 9 split was measured first: the T wave's transform then takes longer than the S wave's 36 MFMAs, the S waves
+// spend a third of the K step at the barrier and the T wave's MFMAs run alone: no faster than four waves.)
+// LDS, the packed weights, the arithmetic and its order are those of conv3x3_wino43_kernel: results are bit-identical.
+constexpr int W4D = 512;
+#ifdef NTK_CL_PROF
+__device__ unsigned long long g_w43d_prof[8][12];
+#endif
+
+template <bool POOL, int TW, int TH, int NSUB, int PWS, int SPXS>
+__global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino43d_kernel(Wino43Args a) {
+    constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 4 * TW + 2, PH = 4 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
+    constexpr int NPXS = NSUB * SPXS;
+    constexpr int NST = (NPX * 2 + 255) / 256;                       // float4 staging slots per thread of the four S waves
+    // many slots per thread (the 1x1x32 shape: 9): a slot's source offset and LDS destination share ONE register -- destination
+    // (float4 units, < 4096) in the low 12 bits, source offset / 16 above it (the host checks that a block's input span is below 16 MB)
+    constexpr bool PACK = NST > 7;
+    constexpr int RAWF = NPXS * 8 + 64;
+    constexpr int VF = 36 * 32 * 8;
+    constexpr int ZF = 36 * 32 * 32;
+    constexpr int LDSF = (2 * RAWF + 2 * VF) > ZF ? (2 * RAWF + 2 * VF) : ZF;
+    static_assert(NTILE == 32, "tile block = 32 MFMA rows");
+    static_assert(LDSF * 4 + 512 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) float s_mem[LDSF];
+    __shared__ int s_sbf[NSUB], s_sby[NSUB], s_sbx[NSUB];
+    float* s_raw = s_mem;                    // [2][RAWF]
+    float* s_V = s_mem + 2 * RAWF;           // [2][VF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave & 3, nbw = wave >> 2;                          // plane group (= SIMD), 32-channel half
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    int cb, sp;
+    if (a.nCB >= 8) {
+        const int kN = a.nCB >> 3;
+        cb = (slot % kN) * 8 + xcd;
+        sp = slot / kN;
+    } else {
+        const int per = 8 / a.nCB;
+        cb = xcd % a.nCB;
+        sp = slot * per + xcd / a.nCB;
+    }
+    if (sp >= a.NS) return;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    if (tid < NSUB) {
+        const int sq = sp * NSUB + tid;
+        if (sq < a.NQ) {
+            const int bx = sq % a.bxN;
+            const int t1 = sq / a.bxN;
+            s_sbf[tid] = t1 / a.byN; s_sby[tid] = 4 * TH * (a.by0 + t1 % a.byN); s_sbx[tid] = 4 * TW * (a.bx0 + bx);
+        } else {
+            s_sbf[tid] = -1; s_sby[tid] = 0; s_sbx[tid] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int sq0 = sp * NSUB;
+    const int f0 = (sq0 / a.bxN) / a.byN;
+    const float* pin = a.in + (size_t)f0 * H * W * Cin;
+    const size_t in_left = ((size_t)(a.frames - f0) * H * W * Cin) * sizeof(float);
+    const unsigned in_bytes = (unsigned)(in_left < 0x40000000ull ? in_left : 0x40000000ull);
+    constexpr unsigned W43_OOB = 0x7ffffff0u;
+    const int n8 = Cin / 8, n8m1 = n8 - 1;
+#ifdef NTK_CL_PROF
+    const bool prof_on = blockIdx.x == 1000 && lane == 0;
+    unsigned long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    // slot table of a staging thread (stid = tid & 255): as in conv3x3_wino43_kernel
+    auto slot_table = [&](unsigned (&soff)[NST], int (&dst)[NST]) {
+        const int stid = tid & 255;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int s = stid + k * 256;
+            const int px = s >> 1, c4 = s & 1;
+            dst[k] = (NPXS * 8) / 4 + (stid & 15);
+            soff[k] = W43_OOB;
+            if (px < NPX) {
+                const int q = px / SPX, lp = px - q * SPX;
+                constexpr int NFULL = PH * TW * 4;
+                int pr, pc;
+                if (lp < NFULL) {
+                    const int seg = lp >> 2;
+                    pr = seg / TW;
+                    pc = 4 * (seg - pr * TW) + (lp & 3);
+                } else {
+                    const int h = lp - NFULL, ri = h >> 1;
+                    pr = ri;
+                    if (PWS & 1) {
+                        const int w = ri & 3;
+                        const int r = (ri & ~3) + (w == 1 ? 2 : w == 2 ? 1 : w);
+                        if (r < PH) pr = r;
+                    }
+                    pc = 4 * TW + (h & 1);
+                }
+                const int fq = s_sbf[q];
+                const int y = s_sby[q] - 1 + pr, x = s_sbx[q] - 1 + pc;
+                dst[k] = (q * SPXS + pr * PWS + 5 * (pc >> 2) + (pc & 3)) * 2 + c4;
+                if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W)
+                    soff[k] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + c4 * 4) * sizeof(float));
+            }
+            if constexpr (PACK) soff[k] = (soff[k] == W43_OOB ? 0xfffff000u : (soff[k] >> 4) << 12) | (unsigned)dst[k];
+        }
+    };
+    auto slot_src = [&](unsigned w) { return PACK ? ((w >> 8) & ~15u) : w; };
+    const unsigned in_window = PACK ? (in_bytes < 0xfffff0u ? in_bytes : 0xfffff0u) : in_bytes;     // the out-of-range marker must stay out of range
+
+    // ---- MFMA lane role (both kinds of wave).  unit = (plane j of this SIMD's nine, 32-channel half nb):
+    //   T waves own units (0..5, 0): 6 x 16 accumulators, 24 MFMAs per K step;
+    //   S waves own units (0..8, 1) and (6..8, 0): 12 x 16 accumulators, 48 MFMAs per K step.
+    const int mrow = lane & 31, kh = lane >> 5;
+    const int vabase = pg * 9 * 256 + mrow * 8 + ((kh ^ ((mrow >> 3) & 1)) * 4);                    // floats, + j * 256
+    f32x16 acc[12];
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.U + (size_t)cb * n8 * 18432), 0, (int)((size_t)n8 * 18432 * sizeof(float)), 0x00020000);
+    const unsigned ubase = (unsigned)lane * 16u + (unsigned)pg * 18432u;                            // bytes, + (2 j + nb) * 1024
+    auto load_unit = [&](int c, int j, int nb) {
+        if constexpr ((W43_ABL & 1) != 0) return f32x4{1.f, 1.f, 1.f, 1.f};
+        else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ubase + (unsigned)(2 * j + nb) * 1024u, c * 73728, 0));
+    };
+    auto load_plane = [&](const float* vcur, int j) {
+        if constexpr ((W43_ABL & 16) != 0) return f32x4{1.f, 1.f, 1.f, 1.f};
+        else return *reinterpret_cast<const f32x4*>(vcur + j * 256);
+    };
+#define W43D_MFMA(C, A, B) C = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0)
+
+    if (wave < 4) {
+        // ================== T waves: staging, the transform of the next K step (first), then 24 MFMAs ==================
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const int pt_u = lane >> 1, pt_c4 = lane & 1;
+        const int pt_tile = (TW == 2 && TH == 2 && NSUB == 8) ? ((pt_u & 7) | ((pt_u & 8) << 1) | ((pt_u & 16) >> 1)) : pt_u;
+        const int pt_q = pt_tile / STILE, pt_tl = pt_tile - pt_q * STILE;
+        const int pt_tr = pt_tl / TW, pt_tc = pt_tl - pt_tr * TW;
+        const int wbase = (pt_q * SPXS + 4 * pt_tr * PWS + 5 * pt_tc) * 8 + pt_c4 * 4;
+        const int vwbase = pt_tile * 8 + ((pt_c4 ^ ((pt_tile >> 3) & 1)) * 4);
+        unsigned soff[NST]; int dst[NST];
+        slot_table(soff, dst);
+        f32x4 stage[NST];
+        auto stage_load = [&](int cs) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + cs * 8), 0, (int)(in_window - cs * 32), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, slot_src(soff[k]), 0, W43_STAGE_AUX));
+        };
+        auto stage_store = [&](int buf) {
+            f32x4* rb = reinterpret_cast<f32x4*>(s_raw + buf * RAWF);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) rb[PACK ? (int)(soff[k] & 4095u) : dst[k]] = stage[k];
+        };
+        {   // prologue: both patches are requested before either is stored: one HBM round trip
+            f32x4 stage1[NST];
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + (n8 > 1 ? 8 : 0)), 0,
+                                                                                   (int)(in_window - (n8 > 1 ? 32 : 0)), 0x00020000);
+            stage_load(0);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) stage1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, slot_src(soff[k]), 0, W43_STAGE_AUX));
+            stage_store(0);
+            f32x4* rb1 = reinterpret_cast<f32x4*>(s_raw + RAWF);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) rb1[PACK ? (int)(soff[k] & 4095u) : dst[k]] = stage1[k];
+        }
+        auto t_loop = [&](auto role_c) {
+            constexpr int ROLE = decltype(role_c)::value;
+            constexpr int NR = ROLE <= 1 ? 4 : 3;
+            f32x4 R1[6], R2[6];
+            auto tr_reads = [&](f32x4 (&D)[4], const float* rp, int b) {
+#pragma unroll
+                for (int s = 0; s < NR; ++s) {
+                    const int aa = ROLE <= 1 ? 1 + s : (ROLE == 2 ? 2 * s : 1 + 2 * s);
+                    D[s] = *reinterpret_cast<const f32x4*>(rp + wbase + (aa * PWS + 5 * (b >> 2) + (b & 3)) * 8);
+                }
+            };
+            auto tr_rows = [&](const f32x4 (&D)[4], int b) {
+                if constexpr (ROLE == 0) {
+                    const f32x4 t1 = D[3] - 4.f * D[1], t2 = D[2] - 4.f * D[0];
+                    R1[b] = t1 + t2; R2[b] = t1 - t2;
+                } else if constexpr (ROLE == 1) {
+                    const f32x4 t3 = D[3] - D[1], u = D[2] - D[0];
+                    R1[b] = t3 + 2.f * u; R2[b] = t3 - 2.f * u;
+                } else if constexpr (ROLE == 2) {
+                    R1[b] = w43_r0(D[0], D[1], D[2]);
+                } else {
+                    R1[b] = w43_r5(D[0], D[1], D[2]);
+                }
+            };
+            auto tr_cols = [&](float* vb, int pi, const f32x4 (&R)[6]) {
+                float* o = vb + pi * 6 * 256 + vwbase;
+                *reinterpret_cast<f32x4*>(o) = w43_r0(R[0], R[2], R[4]);
+                const f32x4 t1 = R[4] - 4.f * R[2], t2 = R[3] - 4.f * R[1];
+                *reinterpret_cast<f32x4*>(o + 256) = t1 + t2;
+                *reinterpret_cast<f32x4*>(o + 2 * 256) = t1 - t2;
+                const f32x4 t3 = R[4] - R[2], u = R[3] - R[1];
+                *reinterpret_cast<f32x4*>(o + 3 * 256) = t3 + 2.f * u;
+                *reinterpret_cast<f32x4*>(o + 4 * 256) = t3 - 2.f * u;
+                *reinterpret_cast<f32x4*>(o + 5 * 256) = w43_r5(R[1], R[3], R[5]);
+            };
+            // the window reads of column b + 1 are in flight while column b's row pass runs (two D sets)
+            f32x4 D[2][4];
+            auto tr_col_pair = [&](const float* rp, int b0, bool more) {      // row pass of columns b0, b0 + 1; requests column b0 + 2
+                tr_reads(D[1], rp, b0 + 1);
+                tr_rows(D[0], b0);
+                if (more) tr_reads(D[0], rp, b0 + 2);
+                tr_rows(D[1], b0 + 1);
+            };
+            auto tr_finish = [&](float* vb) {
+                if constexpr (ROLE == 0) { tr_cols(vb, 1, R1); tr_cols(vb, 2, R2); }
+                else if constexpr (ROLE == 1) { tr_cols(vb, 3, R1); tr_cols(vb, 4, R2); }
+                else if constexpr (ROLE == 2) tr_cols(vb, 0, R1);
+                else tr_cols(vb, 5, R1);
+            };
+            __syncthreads();                                         // patches 0 and 1 are in raw[0], raw[1]
+            tr_reads(D[0], s_raw, 0);
+            tr_col_pair(s_raw, 0, true);
+            tr_col_pair(s_raw, 2, true);
+            tr_col_pair(s_raw, 4, false);
+            tr_finish(s_V);
+            // B operand: two sets of three units, set g for plane group g; group 0 of the NEXT K step is requested during group 1.
+            // A operand: ONE set; a plane's register is re-read for the next group right after its last MFMA has issued.
+            // Transform first, then the wave's 24 MFMAs.  (A VALU instruction issued beside the other wave's MFMA stream waits for
+            // the MFMA in flight, ~30 cycles each: the transform takes ~4 700 cycles of a K step whatever its priority -- s_setprio
+            // changes nothing -- and interleaving the wave's own MFMAs with its pieces was measured 1.5 % slower than this order.)
+            f32x4 Bq[2][3], As[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Bq[0][pl] = load_unit(0, pl, 0);
+            auto t_step = [&](int c8, auto par_c) {
+                constexpr int PAR = decltype(par_c)::value;
+                const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;
+                const int cs = (c8 + 2 < n8) ? c8 + 2 : n8m1;
+                const float* rnext = s_raw + (PAR ^ 1) * RAWF;
+                W43_STAMP(0);
+                __builtin_amdgcn_sched_barrier(0);                   // (the scheduler moves MFMAs across s_barrier otherwise)
+                if constexpr (!(W43_ABL & 8)) __syncthreads();       // V[PAR] and raw[PAR ^ 1] are complete
+                __builtin_amdgcn_sched_barrier(0);
+                W43_STAMP(1);
+                const float* vcur = s_V + PAR * VF + vabase;
+                if constexpr (!(W43_ABL & 4)) stage_load(cs);
+                if constexpr (!(W43_ABL & 2)) {
+                    tr_reads(D[0], rnext, 0);
+                    tr_col_pair(rnext, 0, true);
+                    tr_col_pair(rnext, 2, true);
+                    tr_col_pair(rnext, 4, false);
+                    tr_finish(s_V + (PAR ^ 1) * VF);
+                }
+                __builtin_amdgcn_sched_barrier(0);                   // the operand registers below are not live during the transform
+                W43_STAMP(2);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) As[pl] = load_plane(vcur, pl);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Bq[1][pl] = load_unit(c8, 3 + pl, 0);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[pl], As[pl][q], Bq[0][pl][q]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) { W43D_MFMA(acc[pl], As[pl][3], Bq[0][pl][3]); As[pl] = load_plane(vcur, 3 + pl); }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Bq[0][pl] = load_unit(cn, pl, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[3 + pl], As[pl][q], Bq[1][pl][q]);
+                W43_STAMP(8);
+                if constexpr (!(W43_ABL & 4)) stage_store(PAR);      // raw[PAR] was consumed in the previous K step
+            };
+            W43_STAMP(6);
+            for (int c8 = 0; c8 < n8; c8 += 2) {
+                t_step(c8, ic<0>{});
+                t_step(c8 + 1, ic<1>{});
+            }
+        };
+        if (wave == 0) t_loop(ic<0>{});
+        else if (wave == 1) t_loop(ic<1>{});
+        else if (wave == 2) t_loop(ic<2>{});
+        else t_loop(ic<3>{});
+    } else {
+        // ================== S waves: 48 MFMAs per K step and nothing else ==================
+        // group g = units (3g, 1), (3g + 1, 1), (3g + 2, 1), (6 + g, 0) -> acc[4g .. 4g + 3]
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        f32x4 Bq[2][4], As[4];
+        auto load_Bg = [&](f32x4 (&B)[4], int c, int g) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) B[pl] = load_unit(c, 3 * g + pl, 1);
+            B[3] = load_unit(c, 6 + g, 0);
+        };
+        __syncthreads();                                             // patches 0 and 1 are in raw[0], raw[1]
+        load_Bg(Bq[0], 0, 0);
+        auto s_step = [&](int c8, auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;
+            const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;
+            W43_STAMP(0);
+            __builtin_amdgcn_sched_barrier(0);                       // (the scheduler moves MFMAs across s_barrier otherwise)
+            if constexpr (!(W43_ABL & 8)) __syncthreads();           // V[PAR] and raw[PAR ^ 1] are complete
+            __builtin_amdgcn_sched_barrier(0);
+            W43_STAMP(1);
+            const float* vcur = s_V + PAR * VF + vabase;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) As[pl] = load_plane(vcur, pl);
+            As[3] = load_plane(vcur, 6);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                constexpr int dummy = 0; (void)dummy;
+                const int bs = (PAR + g) & 1;
+                if (g < 2) load_Bg(Bq[bs ^ 1], c8, g + 1); else load_Bg(Bq[bs ^ 1], cn, 0);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) W43D_MFMA(acc[4 * g + u], As[u][q], Bq[bs][u][q]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    W43D_MFMA(acc[4 * g + u], As[u][3], Bq[bs][u][3]);
+                    if (g < 2) As[u] = load_plane(vcur, u < 3 ? 3 * (g + 1) + u : 7 + g);
+                }
+            }
+            W43_STAMP(2);
+            W43_STAMP(3);
+        };
+        W43_STAMP(6);
+        for (int c8 = 0; c8 < n8; c8 += 2) {
+            s_step(c8, ic<0>{});
+            s_step(c8 + 1, ic<1>{});
+        }
+    }
+#undef W43D_MFMA
+
+    // ---- epilogue: one 32-channel half at a time through LDS.  Half 0 sits in the T waves (planes 0..5 of their nine) and the S
+    // waves (planes 6..8); its output transform is run by the T waves, whose accumulators are dead by then (the S waves still hold
+    // half 1); half 1's by the S waves.  thread = (tile, four adjacent channels)
+    float* sZ = s_mem;
+    const int col = lane & 31;
+    W43_STAMP(4);
+    auto z_store = [&](const f32x16& v, int plane) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
+            sZ[((9 * pg + plane) * 32 + m) * 32 + col] = v[r];
+        }
+    };
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();
+        if (nb == 0) {
+            if (nbw == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) z_store(acc[j], j);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) z_store(acc[4 * g + 3], 6 + g);
+            }
+        } else if (nbw == 1) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) z_store(acc[4 * g + pl], 3 * g + pl);
+        }
+        __syncthreads();
+        if (nbw == nb) {
+            const int et = tid & 255;
+            const int m = et >> 3, cq = et & 7;
+            const int n = 64 * cb + 32 * nb + 4 * cq;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+            const int mq = m / STILE, ml = m - mq * STILE;
+            const int f = s_sbf[mq];
+            if (f >= 0) {
+                const f32x4* zp = reinterpret_cast<const f32x4*>(sZ + m * 32 + 4 * cq);
+                f32x4 z[4][6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    f32x4 mm[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) mm[i] = zp[(i * 6 + j) * 256];
+                    const f32x4 s12 = mm[1] + mm[2], d12 = mm[1] - mm[2], s34 = mm[3] + mm[4], d34 = mm[3] - mm[4];
+                    z[0][j] = mm[0] + s12 + s34;
+                    z[1][j] = d12 + 2.f * d34;
+                    z[2][j] = s12 + 4.f * s34;
+                    z[3][j] = d12 + 8.f * d34 + mm[5];
+                }
+                f32x4 y[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 s12 = z[k][1] + z[k][2], d12 = z[k][1] - z[k][2], s34 = z[k][3] + z[k][4], d34 = z[k][3] - z[k][4];
+                    y[k][0] = z[k][0] + s12 + s34;
+                    y[k][1] = d12 + 2.f * d34;
+                    y[k][2] = s12 + 4.f * s34;
+                    y[k][3] = d12 + 8.f * d34 + z[k][5];
+                }
+                const int tr = ml / TW, tc = ml - tr * TW;
+                const int oy = s_sby[mq] + 4 * tr, ox = s_sbx[mq] + 4 * tc;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (POOL) {
+                    float* op = a.out + (((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n;
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = fmaxf(fmaxf(y[2 * aa][2 * b][e], y[2 * aa][2 * b + 1][e]), fmaxf(y[2 * aa + 1][2 * b][e], y[2 * aa + 1][2 * b + 1][e]));
+                            v = v + bv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
+                            W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * (W >> 1) + b) * Cout), v);
+                        }
+                } else {
+                    float* op = a.out + (((size_t)f * H + oy) * W + ox) * Cout + n;
+#pragma unroll
+                    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            f32x4 v = y[aa][b] + bv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
+                            W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * W + b) * Cout), v);
+                        }
+                }
+            }
+        }
+    }
+#ifdef NTK_CL_PROF
+    W43_STAMP(5);
+    if (prof_on)
+        for (int i = 0; i < 12; ++i) g_w43d_prof[wave][i] = prof_acc[i];
+#endif
+}
+
 }  // namespace
 
 #ifdef NTK_CL_PROF
 extern "C" int ntk_vgg_wino43_prof(unsigned long long* out64) {
     return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_w43_prof), 96 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
+}
+#endif
+
+#ifdef NTK_CL_PROF
+extern "C" int ntk_vgg_wino43d_prof(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_w43d_prof), 96 * sizeof(unsigned long long)) == hipSuccess ? NTK_OK : NTK_ERR_HIP;
 }
 #endif
 
@@ -607,8 +1054,17 @@ static int wino43_launch(const float* in, const float* u_packed, const float* bi
     else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
     const long long grid = slots * 8;
     NTK_REQUIRE(grid < (1ll << 31), NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino43_f32: grid too large");
-#define W43_LAUNCH(POOL_, TW_, TH_, NSUB_, PWS_, SPXS_) \
-    conv3x3_wino43_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4T, 0, (hipStream_t)stream>>>(a)
+    const int variant = [] { const char* e = getenv("NTK_W43_VARIANT"); return e ? atoi(e) : 0; }();     // dev switch, read per call
+    // the eight-wave kernel packs a staging slot into one register on the 1x1x32 shape: a block's input span (the frames its 32
+    // tiles touch) must stay below 16 MB there
+    const long long tpf = (long long)a.bxN * a.byN;
+    const long long span = ((32 + tpf - 1) / tpf + 1) * (long long)H * W * cin * (long long)sizeof(float);
+    const bool dual = variant == 1 && (shape != 3 || span <= 0xfffff0ll);
+#define W43_LAUNCH(POOL_, TW_, TH_, NSUB_, PWS_, SPXS_)                                                                       \
+    do {                                                                                                                      \
+        if (dual) conv3x3_wino43d_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4D, 0, (hipStream_t)stream>>>(a); \
+        else conv3x3_wino43_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4T, 0, (hipStream_t)stream>>>(a);  \
+    } while (0)
     // PWS / SPXS: pixel-slot strides of a patch row / a sub-block, chosen so that the sixteen lanes of every window
     // ds_read_b128 fall on sixteen different 16-byte bank slots (tile stride 10 slots; row / sub-block strides = 8 / 6 mod 16)
     if (shape == 0) { if (fuse_pool) W43_LAUNCH(true, 8, 4, 1, 42, 18 * 42); else W43_LAUNCH(false, 8, 4, 1, 42, 18 * 42); }
