@@ -556,13 +556,43 @@ __global__ __launch_bounds__(W4T) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // With one wave per SIMD every wait of that wave (LDS latency of the A / window reads, the U loads, the barrier) is an idle
 // matrix pipe.  Here a SIMD's nine planes x two 32-channel halves = 18 accumulator units are split UNEVENLY between its two
 // waves, and the rest of the work the other way round:
-//   waves 0..3 ("T"): 6 units (24 MFMAs per K step); the patch staging (global -> registers -> LDS) and the input transform of
-//                     the next K step (task = wave: plane rows (1,2), (3,4), 0, 5), done FIRST in a K step;
+//   waves 0..3 ("T"): 5 or 7 units (20 / 28 MFMAs per K step); the patch staging (global -> registers -> LDS) and the input
+//                     transform of the next K step (task = wave: plane rows (1,2), (3,4) -- 5 units --, 0, 5 -- 7 units),
+//                     done FIRST in a K step;
 //   waves 4..7 ("S"): 12 units (48 MFMAs per K step) and nothing else: the matrix pipe has their work while the T wave of the
 //                     same SIMD waits for its window reads and runs its row / column passes.
 // (An even 9 / 9 split was measured first: the T wave's transform then takes longer than the S wave's 36 MFMAs, the S waves
 // spend a third of the K step at the barrier and the T wave's MFMAs run alone: no faster than four waves.)
 // LDS, the packed weights, the arithmetic and its order are those of conv3x3_wino43_kernel: results are bit-identical.
+
+// Packed fp32 forms of the transform's arithmetic with the negations folded into the instruction.  Left to itself the compiler
+// splits a vector subtraction into scalar v_sub_f32 and materialises negations with v_xor_b32: 164 VALU instructions per K
+// step of a pair task where 96 packed ones do.  Beside another wave's fp32 MFMA stream every VALU instruction waits for the
+// MFMA in flight, so the COUNT is what the transform costs (the results are the same bits: the same fused operations).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define W43_PK(name, text)                                                                    \
+    __device__ __forceinline__ f32x4 name(f32x4 a, f32x4 b) {                                  \
+        f32x2 lo, hi;                                                                         \
+        asm(text : "=v"(lo) : "v"(a.xy), "v"(b.xy));                                           \
+        asm(text : "=v"(hi) : "v"(a.zw), "v"(b.zw));                                           \
+        return f32x4{lo.x, lo.y, hi.x, hi.y};                                                 \
+    }
+W43_PK(w43_add, "v_pk_add_f32 %0, %1, %2")                                                     // a + b
+W43_PK(w43_sub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")                           // a - b
+W43_PK(w43_fma4, "v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]")                             // 4 a + b
+W43_PK(w43_fnma4, "v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]")   // b - 4 a
+W43_PK(w43_fma2, "v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]")                             // 2 a + b
+W43_PK(w43_fnma2, "v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]")   // b - 2 a
+#undef W43_PK
+__device__ __forceinline__ f32x4 w43_fnma5(f32x4 a, f32x4 b) {                                 // b - 5 a
+    f32x2 lo, hi;
+    const f32x2 k5 = {5.f, 5.f};
+    asm("v_pk_fma_f32 %0, %1, %3, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(lo) : "v"(a.xy), "v"(b.xy), "s"(k5));
+    asm("v_pk_fma_f32 %0, %1, %3, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(hi) : "v"(a.zw), "v"(b.zw), "s"(k5));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ f32x4 w43p_r0(f32x4 d0, f32x4 d2, f32x4 d4) { return w43_fma4(d0, w43_fnma5(d2, d4)); }     // 4 d0 + (d4 - 5 d2)
+
 constexpr int W4D = 512;
 #ifdef NTK_CL_PROF
 __device__ unsigned long long g_w43d_prof[8][12];
@@ -667,7 +697,7 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned in_window = PACK ? (in_bytes < 0xfffff0u ? in_bytes : 0xfffff0u) : in_bytes;     // the out-of-range marker must stay out of range
 
     // ---- MFMA lane role (both kinds of wave).  unit = (plane j of this SIMD's nine, 32-channel half nb):
-    //   T waves own units (0..5, 0): 6 x 16 accumulators, 24 MFMAs per K step;
+    //   T waves own units (0..4, 0), waves 2, 3 also (5, 0) and unit (5, 0) of waves 0, 1: 5 / 7 x 16 accumulators;
     //   S waves own units (0..8, 1) and (6..8, 0): 12 x 16 accumulators, 48 MFMAs per K step.
     const int mrow = lane & 31, kh = lane >> 5;
     const int vabase = pg * 9 * 256 + mrow * 8 + ((kh ^ ((mrow >> 3) & 1)) * 4);                    // floats, + j * 256
@@ -686,9 +716,9 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define W43D_MFMA(C, A, B) C = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0)
 
     if (wave < 4) {
-        // ================== T waves: staging, the transform of the next K step (first), then 24 MFMAs ==================
+        // ================== T waves: staging, the transform of the next K step (first), then 20 / 28 MFMAs ==================
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < 7; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         const int pt_u = lane >> 1, pt_c4 = lane & 1;
@@ -734,28 +764,26 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             };
             auto tr_rows = [&](const f32x4 (&D)[4], int b) {
-                if constexpr (ROLE == 0) {
-                    const f32x4 t1 = D[3] - 4.f * D[1], t2 = D[2] - 4.f * D[0];
-                    R1[b] = t1 + t2; R2[b] = t1 - t2;
-                } else if constexpr (ROLE == 1) {
-                    const f32x4 t3 = D[3] - D[1], u = D[2] - D[0];
-                    R1[b] = t3 + 2.f * u; R2[b] = t3 - 2.f * u;
-                } else if constexpr (ROLE == 2) {
-                    R1[b] = w43_r0(D[0], D[1], D[2]);
-                } else {
-                    R1[b] = w43_r5(D[0], D[1], D[2]);
+                if constexpr (ROLE == 0) {                          // rows 1, 2:  (d4 - 4 d2) +- (d3 - 4 d1)
+                    const f32x4 t1 = w43_fnma4(D[1], D[3]), t2 = w43_fnma4(D[0], D[2]);
+                    R1[b] = w43_add(t1, t2); R2[b] = w43_sub(t1, t2);
+                } else if constexpr (ROLE == 1) {                   // rows 3, 4:  (d4 - d2) +- 2 (d3 - d1)
+                    const f32x4 t3 = w43_sub(D[3], D[1]), u = w43_sub(D[2], D[0]);
+                    R1[b] = w43_fma2(u, t3); R2[b] = w43_fnma2(u, t3);
+                } else {                                            // row 0 (5): 4 d0 + (d4 - 5 d2)  (4 d1 + (d5 - 5 d3))
+                    R1[b] = w43p_r0(D[0], D[1], D[2]);
                 }
             };
             auto tr_cols = [&](float* vb, int pi, const f32x4 (&R)[6]) {
                 float* o = vb + pi * 6 * 256 + vwbase;
-                *reinterpret_cast<f32x4*>(o) = w43_r0(R[0], R[2], R[4]);
-                const f32x4 t1 = R[4] - 4.f * R[2], t2 = R[3] - 4.f * R[1];
-                *reinterpret_cast<f32x4*>(o + 256) = t1 + t2;
-                *reinterpret_cast<f32x4*>(o + 2 * 256) = t1 - t2;
-                const f32x4 t3 = R[4] - R[2], u = R[3] - R[1];
-                *reinterpret_cast<f32x4*>(o + 3 * 256) = t3 + 2.f * u;
-                *reinterpret_cast<f32x4*>(o + 4 * 256) = t3 - 2.f * u;
-                *reinterpret_cast<f32x4*>(o + 5 * 256) = w43_r5(R[1], R[3], R[5]);
+                *reinterpret_cast<f32x4*>(o) = w43p_r0(R[0], R[2], R[4]);
+                const f32x4 t1 = w43_fnma4(R[2], R[4]), t2 = w43_fnma4(R[1], R[3]);
+                *reinterpret_cast<f32x4*>(o + 256) = w43_add(t1, t2);
+                *reinterpret_cast<f32x4*>(o + 2 * 256) = w43_sub(t1, t2);
+                const f32x4 t3 = w43_sub(R[4], R[2]), u = w43_sub(R[3], R[1]);
+                *reinterpret_cast<f32x4*>(o + 3 * 256) = w43_fma2(u, t3);
+                *reinterpret_cast<f32x4*>(o + 4 * 256) = w43_fnma2(u, t3);
+                *reinterpret_cast<f32x4*>(o + 5 * 256) = w43p_r0(R[1], R[3], R[5]);
             };
             // the window reads of column b + 1 are in flight while column b's row pass runs (two D sets)
             f32x4 D[2][4];
@@ -782,9 +810,32 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // Transform first, then the wave's 24 MFMAs.  (A VALU instruction issued beside the other wave's MFMA stream waits for
             // the MFMA in flight, ~30 cycles each: the transform takes ~4 700 cycles of a K step whatever its priority -- s_setprio
             // changes nothing -- and interleaving the wave's own MFMAs with its pieces was measured 1.5 % slower than this order.)
-            f32x4 Bq[2][3], As[3];
+            // Units: the pair tasks (ROLE 0, 1) issue twice the VALU instructions of the single-row ones, so their waves hand
+            // unit (5, 0) to the wave two above (same arithmetic, another owner): 5 units = 20 MFMAs per K step beside 96 VALU
+            // instructions, against 7 units = 28 MFMAs beside 48.
+            constexpr bool HEAVY = ROLE <= 1;
+            constexpr int NG1 = HEAVY ? 2 : 4;                       // units of group 1: planes 3, 4 | planes 3, 4, 5 + the adopted one
+            f32x4 Bq0[3], Bq1[NG1], As[NG1 > 3 ? NG1 : 3];
+            const int vxbase = (ROLE & 1) * 9 * 256 + 5 * 256 + mrow * 8 + ((kh ^ ((mrow >> 3) & 1)) * 4);    // plane 5 of wave ROLE - 2
+            const unsigned uxbase = (unsigned)lane * 16u + (unsigned)(ROLE & 1) * 18432u + 10u * 1024u;        // unit (5, 0) of wave ROLE - 2
+            auto load_g1 = [&](int c, const float* vplanes) {          // B of group 1 (vplanes == nullptr) or its A planes
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) Bq[0][pl] = load_unit(0, pl, 0);
+                for (int u = 0; u < NG1; ++u) {
+                    if (u < 3) {
+                        if (vplanes) As[u] = load_plane(vplanes + vabase, 3 + u); else Bq1[u] = load_unit(c, 3 + u, 0);
+                    } else {
+                        if (vplanes) {
+                            if constexpr ((W43_ABL & 16) != 0) As[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+                            else As[u] = *reinterpret_cast<const f32x4*>(vplanes + vxbase);
+                        } else {
+                            if constexpr ((W43_ABL & 1) != 0) Bq1[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+                            else Bq1[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uxbase, c * 73728, 0));
+                        }
+                    }
+                }
+            };
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Bq0[pl] = load_unit(0, pl, 0);
             auto t_step = [&](int c8, auto par_c) {
                 constexpr int PAR = decltype(par_c)::value;
                 const int cn = (c8 + 1 < n8) ? c8 + 1 : 0;
@@ -808,20 +859,20 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 W43_STAMP(2);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) As[pl] = load_plane(vcur, pl);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Bq[1][pl] = load_unit(c8, 3 + pl, 0);
+                load_g1(c8, nullptr);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[pl], As[pl][q], Bq[0][pl][q]);
+                    for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[pl], As[pl][q], Bq0[pl][q]);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) { W43D_MFMA(acc[pl], As[pl][3], Bq[0][pl][3]); As[pl] = load_plane(vcur, 3 + pl); }
+                for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[pl], As[pl][3], Bq0[pl][3]);
+                load_g1(0, s_V + PAR * VF);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Bq[0][pl] = load_unit(cn, pl, 0);
+                for (int pl = 0; pl < 3; ++pl) Bq0[pl] = load_unit(cn, pl, 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[3 + pl], As[pl][q], Bq[1][pl][q]);
+                    for (int u = 0; u < NG1; ++u) W43D_MFMA(acc[3 + u], As[u][q], Bq1[u][q]);
                 W43_STAMP(8);
                 if constexpr (!(W43_ABL & 4)) stage_store(PAR);      // raw[PAR] was consumed in the previous K step
             };
@@ -905,9 +956,13 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();
         if (nb == 0) {
-            if (nbw == 0) {
+            if (nbw == 0) {                                          // T waves: planes 0..4 (+ 5, + plane 5 of wave pg - 2)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) z_store(acc[j], j);
+                for (int j = 0; j < 5; ++j) z_store(acc[j], j);
+                if (pg >= 2) {
+                    z_store(acc[5], 5);
+                    z_store(acc[6], 5 - 18);
+                }
             } else {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) z_store(acc[4 * g + 3], 6 + g);
