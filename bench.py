@@ -461,7 +461,7 @@ def main():
                        **({"features_roi": "conv4_3 computed in the 25 of 49 output tiles extract_features reads (optional; the flops "
                                            "in `roofline` are reduced accordingly; NOT the headline configuration)"}
                           if (args.features_roi and getattr(trk, "features_roi", False)) else {})},
-            "roofline": {"bound": "mfma", "kernel": (("conv3x3_wino43_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(4x4,3x3) layers)"
+            "roofline": {"bound": "mfma", "kernel": (("conv3x3_wino43d_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(4x4,3x3) layers)"
                                                       if args.conv_algo == "winograd" else
                                                       ("conv3x3_wino_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(2x2,3x3) layers)"
                                                        if args.conv_algo == "winograd2" else "conv3x3_relu_dma_kernel (VGG trunk, 10 layers)"))

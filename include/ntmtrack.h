@@ -97,6 +97,12 @@ int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_packed, cons
 int ntk_vgg_conv3x3_relu_wino43_window_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                            int frames, int H, int W, int cin, int cout, int fuse_pool,
                                            int y0, int x0, int y1, int x1, void* stream);
+/* The general form: window + kernel form.  waves = 8 (what the two entries above launch): eight waves per workgroup, two per
+ * SIMD -- one runs the patch staging and the input transform beside a third of the MFMAs, the other two thirds of the MFMAs and
+ * nothing else; waves = 4: round 2's one-wave-per-SIMD kernel.  Same bits either way (tests/test_vgg_gpu.py). */
+int ntk_vgg_conv3x3_relu_wino43_form_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                         int frames, int H, int W, int cin, int cout, int fuse_pool,
+                                         int y0, int x0, int y1, int x1, int waves, void* stream);
 
 /* slim.max_pool2d [2,2] stride 2 on NHWC fp32 (vgg.py:155-161) as its own launch (ntk_maxpool2x2).
  * The trunk fuses the pool into the epilogue of conv1_2 / conv2_2 / conv3_3 (fuse_pool); this entry point is the

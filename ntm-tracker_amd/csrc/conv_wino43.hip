@@ -24,7 +24,6 @@
 //     A^T M A, bias, ReLU (+ 2x2 pool inside the 4x4 tile) and store one float4 per pixel, NHWC.
 #include "common.h"
 #include <type_traits>
-#include <cstdlib>
 
 // Diagnostic build only (make prof, -DNTK_CL_PROF): lane 0 of every wave of ONE workgroup accumulates s_memtime deltas per
 // section of the K loop into g_w43_prof[wave][section]; ntk_vgg_wino43_prof() copies them out (read SHARES, not totals).
@@ -807,9 +806,11 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             tr_finish(s_V);
             // B operand: two sets of three units, set g for plane group g; group 0 of the NEXT K step is requested during group 1.
             // A operand: ONE set; a plane's register is re-read for the next group right after its last MFMA has issued.
-            // Transform first, then the wave's 24 MFMAs.  (A VALU instruction issued beside the other wave's MFMA stream waits for
-            // the MFMA in flight, ~30 cycles each: the transform takes ~4 700 cycles of a K step whatever its priority -- s_setprio
-            // changes nothing -- and interleaving the wave's own MFMAs with its pieces was measured 1.5 % slower than this order.)
+            // Order of a K step: the previous step's group 1 (operands already in registers), the transform, group 0.  While the S
+            // wave has MFMAs to issue the SIMD alternates strictly -- ONE VALU instruction of this wave per MFMA of the other (s_setprio
+            // changes nothing) -- so the transform's first 48 VALU instructions take the S wave's 3 072 MFMA cycles whatever they are,
+            // the rest run at full rate, and what decides the K step is how much of this wave's own work is left AFTER that:
+            // interleaving its MFMAs with the transform's pieces was measured 1.5 % slower than transform-first.
             // Units: the pair tasks (ROLE 0, 1) issue twice the VALU instructions of the single-row ones, so their waves hand
             // unit (5, 0) to the wave two above (same arithmetic, another owner): 5 units = 20 MFMAs per K step beside 96 VALU
             // instructions, against 7 units = 28 MFMAs beside 48.
@@ -847,40 +848,48 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
                 W43_STAMP(1);
                 const float* vcur = s_V + PAR * VF + vabase;
+                if constexpr (!(W43_ABL & 2)) tr_reads(D[0], rnext, 0);
+                // the previous K step's group 1 (its A planes and B units are in registers): the matrix pipe has work while this
+                // wave's first window reads and the S wave's first A reads are in flight
+                if (PAR == 1 || c8 > 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int u = 0; u < NG1; ++u) W43D_MFMA(acc[3 + u], As[u][q], Bq1[u][q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) As[pl] = load_plane(vcur, pl);
                 if constexpr (!(W43_ABL & 4)) stage_load(cs);
                 if constexpr (!(W43_ABL & 2)) {
-                    tr_reads(D[0], rnext, 0);
                     tr_col_pair(rnext, 0, true);
                     tr_col_pair(rnext, 2, true);
                     tr_col_pair(rnext, 4, false);
                     tr_finish(s_V + (PAR ^ 1) * VF);
                 }
-                __builtin_amdgcn_sched_barrier(0);                   // the operand registers below are not live during the transform
+                __builtin_amdgcn_sched_barrier(0);
                 W43_STAMP(2);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) As[pl] = load_plane(vcur, pl);
                 load_g1(c8, nullptr);
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[pl], As[pl][q], Bq0[pl][q]);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[pl], As[pl][3], Bq0[pl][3]);
-                load_g1(0, s_V + PAR * VF);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Bq0[pl] = load_unit(cn, pl, 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int u = 0; u < NG1; ++u) W43D_MFMA(acc[3 + u], As[u][q], Bq1[u][q]);
-                W43_STAMP(8);
+                    for (int pl = 0; pl < 3; ++pl) W43D_MFMA(acc[pl], As[pl][q], Bq0[pl][q]);
                 if constexpr (!(W43_ABL & 4)) stage_store(PAR);      // raw[PAR] was consumed in the previous K step
+                load_g1(0, s_V + PAR * VF);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Bq0[pl] = load_unit(cn, pl, 0);
+                W43_STAMP(8);
             };
             W43_STAMP(6);
             for (int c8 = 0; c8 < n8; c8 += 2) {
                 t_step(c8, ic<0>{});
                 t_step(c8 + 1, ic<1>{});
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < NG1; ++u) W43D_MFMA(acc[3 + u], As[u][q], Bq1[u][q]);
         };
         if (wave == 0) t_loop(ic<0>{});
         else if (wave == 1) t_loop(ic<1>{});
@@ -1070,7 +1079,8 @@ extern "C" int ntk_vgg_pack_weights_wino43(const float* w_hwio, float* u_packed,
 }
 
 static int wino43_launch(const float* in, const float* u_packed, const float* bias, float* out,
-                         int frames, int H, int W, int cin, int cout, int fuse_pool, int y0, int x0, int y1, int x1, void* stream) {
+                         int frames, int H, int W, int cin, int cout, int fuse_pool, int y0, int x0, int y1, int x1, int waves, void* stream) {
+    NTK_REQUIRE(waves == 4 || waves == 8, NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino43: waves=%d (4 or 8 per workgroup)", waves);
     NTK_REQUIRE(in && u_packed && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_wino43_f32: null pointer");
     NTK_REQUIRE(ntk_aligned16(in) && ntk_aligned16(u_packed) && ntk_aligned16(out), NTK_ERR_BAD_PTR,
                 "ntk_vgg_conv3x3_relu_wino43_f32: 16-byte alignment");
@@ -1109,12 +1119,11 @@ static int wino43_launch(const float* in, const float* u_packed, const float* bi
     else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
     const long long grid = slots * 8;
     NTK_REQUIRE(grid < (1ll << 31), NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino43_f32: grid too large");
-    const int variant = [] { const char* e = getenv("NTK_W43_VARIANT"); return e ? atoi(e) : 0; }();     // dev switch, read per call
     // the eight-wave kernel packs a staging slot into one register on the 1x1x32 shape: a block's input span (the frames its 32
     // tiles touch) must stay below 16 MB there
     const long long tpf = (long long)a.bxN * a.byN;
     const long long span = ((32 + tpf - 1) / tpf + 1) * (long long)H * W * cin * (long long)sizeof(float);
-    const bool dual = variant == 1 && (shape != 3 || span <= 0xfffff0ll);
+    const bool dual = waves == 8 && (shape != 3 || span <= 0xfffff0ll);
 #define W43_LAUNCH(POOL_, TW_, TH_, NSUB_, PWS_, SPXS_)                                                                       \
     do {                                                                                                                      \
         if (dual) conv3x3_wino43d_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4D, 0, (hipStream_t)stream>>>(a); \
@@ -1133,7 +1142,7 @@ static int wino43_launch(const float* in, const float* u_packed, const float* bi
 
 extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                                int frames, int H, int W, int cin, int cout, int fuse_pool, void* stream) {
-    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, 0, 0, H, W, stream);
+    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, 0, 0, H, W, 8, stream);
 }
 
 // The same layer computed only inside the window [y0, y1) x [x0, x1) of the (un-pooled) output, multiples of 4: every 4x4 output
@@ -1143,5 +1152,14 @@ extern "C" int ntk_vgg_conv3x3_relu_wino43_f32(const float* in, const float* u_p
 extern "C" int ntk_vgg_conv3x3_relu_wino43_window_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                                       int frames, int H, int W, int cin, int cout, int fuse_pool,
                                                       int y0, int x0, int y1, int x1, void* stream) {
-    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, y0, x0, y1, x1, stream);
+    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, y0, x0, y1, x1, 8, stream);
+}
+
+// The general form: window + the kernel form.  waves = 8 (what the two entries above use): conv3x3_wino43d_kernel, two waves per
+// SIMD; waves = 4: conv3x3_wino43_kernel, one wave per SIMD (round 2's kernel; also what a 1x1-tile-block layer whose blocks span
+// more than 16 MB of input falls back to).  The two forms give the same bits.
+extern "C" int ntk_vgg_conv3x3_relu_wino43_form_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                                    int frames, int H, int W, int cin, int cout, int fuse_pool,
+                                                    int y0, int x0, int y1, int x1, int waves, void* stream) {
+    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, y0, x0, y1, x1, waves, stream);
 }

@@ -109,15 +109,22 @@ def pack_weights_wino43(w_hwio):
     return u
 
 
-def conv3x3_relu_wino43(x, u_packed, bias, cin, cout, fuse_pool=False, out=None, window=None):
+def conv3x3_relu_wino43(x, u_packed, bias, cin, cout, fuse_pool=False, out=None, window=None, waves=None):
     """Same operator as conv3x3_relu by fused Winograd F(4x4,3x3) (csrc/conv_wino43.hip).
-    window = (y0, x0, y1, x1), multiples of 4: compute only that part of the un-pooled output (the rest of `out` is not touched)."""
+    window = (y0, x0, y1, x1), multiples of 4: compute only that part of the un-pooled output (the rest of `out` is not touched).
+    waves = 4 / 8: the one- / two-waves-per-SIMD form of the kernel (default: 8; same bits)."""
     F, H, W, C = x.shape
     if C != cin:
         raise _lib.NtkError("conv3x3_relu_wino43: input has %d channels, layer expects %d" % (C, cin))
     oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
     if out is None:
         out = torch.empty((F, oh, ow, cout), device=x.device, dtype=torch.float32)
+    if waves is not None:
+        y0, x0, y1, x1 = [int(v) for v in window] if window is not None else (0, 0, H, W)
+        _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_wino43_form_f32(_lib.ptr(x), _lib.ptr(u_packed), _lib.ptr(bias), _lib.ptr(out),
+                                                                   F, H, W, cin, cout, 1 if fuse_pool else 0, y0, x0, y1, x1,
+                                                                   int(waves), _lib.stream()), "ntk_vgg_conv3x3_relu_wino43_form_f32")
+        return out
     if window is not None:
         y0, x0, y1, x1 = [int(v) for v in window]
         _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_wino43_window_f32(_lib.ptr(x), _lib.ptr(u_packed), _lib.ptr(bias), _lib.ptr(out),

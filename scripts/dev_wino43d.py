@@ -1,4 +1,4 @@
-"""Dev: the eight-wave F(4x4,3x3) kernel (NTK_W43_VARIANT=1) against the four-wave one: bitwise equality on test shapes, then
+"""Dev: the eight-wave F(4x4,3x3) kernel against the four-wave one: bitwise equality on test shapes, then
 per-layer timing of both at the trunk's shapes.  usage: python scripts/dev_wino43d.py [frames]"""
 import sys, os
 import numpy as np
@@ -11,8 +11,7 @@ rng = np.random.default_rng(0)
 
 
 def run(variant, *args, **kw):
-    os.environ["NTK_W43_VARIANT"] = str(variant)
-    return vgg.conv3x3_relu_wino43(*args, **kw)
+    return vgg.conv3x3_relu_wino43(*args, waves=8 if variant else 4, **kw)
 
 
 bad = 0

@@ -1,5 +1,5 @@
 """Dev: per-section cycles of the eight-wave F(4x4,3x3) kernel's K loop (diagnostic library: make -C ntm-tracker_amd/csrc prof;
-run with NTK_LIB_PATH=ntm-tracker_amd/libntmtrack_hip_prof.so NTK_W43_VARIANT=1).  One workgroup, all eight waves."""
+run with NTK_LIB_PATH=ntm-tracker_amd/libntmtrack_hip_prof.so).  One workgroup, all eight waves."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,6 @@ w = torch.randn((3, 3, cin, cout), device=dev) * 0.02
 b = torch.zeros(cout, device=dev)
 up = vgg.pack_weights_wino43(w)
 out = torch.empty((F, H, H, cout), device=dev)
-os.environ["NTK_W43_VARIANT"] = "1"
 for _ in range(2):
     vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out)
 torch.cuda.synchronize()

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ntmtrack import vgg
 dev = torch.device("cuda")
-os.environ["NTK_W43_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "1"
+WAVES = 8 if (sys.argv[1] if len(sys.argv) > 1 else "1") == "1" else 4
 res = []
 for (H, cin, cout) in ((56, 256, 256), (224, 64, 64), (28, 512, 512)):
     x = torch.randn((640, H, H, cin), device=dev)
@@ -12,12 +12,12 @@ for (H, cin, cout) in ((56, 256, 256), (224, 64, 64), (28, 512, 512)):
     b = torch.zeros(cout, device=dev)
     up = vgg.pack_weights_wino43(w)
     out = torch.empty((640, H, H, cout), device=dev)
-    vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out)
+    vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, waves=WAVES)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
-        vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out)
+        vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, waves=WAVES)
     e1.record()
     torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1) / 3)

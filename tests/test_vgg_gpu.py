@@ -180,8 +180,12 @@ def test_winograd_rejects_bad_shapes(cuda):
     (1, 112, 112, 64, 128, False),  # conv2-like
     (3, 56, 56, 128, 256, True),    # conv3-like, fused pool
     (2, 28, 28, 256, 512, False),   # conv4-like: 32 K steps
+    (1, 180, 180, 64, 64, False),   # 45 x 45 tiles: 1x1x32 blocks spanning > 16 MB of input (the eight-wave form hands over to the four-wave kernel)
 ])
-def test_conv3x3_relu_winograd43_matches_oracle(cuda, F, H, W, cin, cout, pool):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_conv3x3_relu_winograd43_matches_oracle(cuda, F, H, W, cin, cout, pool, waves):
+    """Both forms of the kernel (csrc/conv_wino43.hip: eight waves per workgroup = the default, four = round 2's) against the
+    float64 oracle, and against each other bit for bit."""
     from ntmtrack import vgg
     rng = np.random.default_rng(9)
     x = rng.standard_normal((F, H, W, cin)).astype(np.float32)
@@ -192,9 +196,14 @@ def test_conv3x3_relu_winograd43_matches_oracle(cuda, F, H, W, cin, cout, pool):
         ref = O.maxpool2x2(ref)
     assert vgg.wino43_supported(cin, cout, H, W)
     up = vgg.pack_weights_wino43(torch.from_numpy(w).to(cuda))
-    got = vgg.conv3x3_relu_wino43(torch.from_numpy(x).to(cuda), up, torch.from_numpy(b).to(cuda), cin, cout, fuse_pool=pool).cpu().numpy()
+    tx, tb = torch.from_numpy(x).to(cuda), torch.from_numpy(b).to(cuda)
+    got_t = vgg.conv3x3_relu_wino43(tx, up, tb, cin, cout, fuse_pool=pool, waves=waves)
+    got = got_t.cpu().numpy()
     assert got.shape == ref.shape
     assert _rel(got, ref) < 3e-5
+    if waves == 8:
+        assert torch.equal(got_t, vgg.conv3x3_relu_wino43(tx, up, tb, cin, cout, fuse_pool=pool))           # the default IS this form
+        assert torch.equal(got_t, vgg.conv3x3_relu_wino43(tx, up, tb, cin, cout, fuse_pool=pool, waves=4))  # same bits
 
 
 def test_winograd43_rejects_bad_shapes(cuda):
@@ -257,13 +266,14 @@ def test_winograd43_window_equals_whole_frame_inside_and_touches_nothing_outside
         b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(cuda)
         up = vgg.pack_weights_wino43(w)
         full = vgg.conv3x3_relu_wino43(x, up, b, cin, cout)
-        out = torch.full_like(full, -7.0)
-        vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=win)
         y0, x0, y1, x1 = win
         mask = torch.zeros((H, W), dtype=torch.bool, device=cuda)
         mask[y0:y1, x0:x1] = True
-        assert torch.equal(out[:, mask], full[:, mask]), win
-        assert bool((out[:, ~mask] == -7.0).all()), win
+        for waves in (None, 4, 8):
+            out = torch.full_like(full, -7.0)
+            vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=win, waves=waves)
+            assert torch.equal(out[:, mask], full[:, mask]), (win, waves)
+            assert bool((out[:, ~mask] == -7.0).all()), (win, waves)
     with pytest.raises(_lib.NtkError):
         vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=(0, 2, 20, 8))      # not a multiple of 4
     with pytest.raises(_lib.NtkError):
