@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--model", default="ntm", choices=["ntm", "dnc"],
                     help="ntm = BASELINE configs[1] (the headline metric); dnc = configs[2] (DNC 256x64, 4 read heads), reported for reference")
+    ap.add_argument("--wino-waves", type=int, default=0, choices=[0, 4, 8], help="form of the F(4x4) kernel (0 = library default = 8)")
     ap.add_argument("--conv-algo", default="winograd", choices=["winograd", "winograd2", "direct"],
                     help="fp32 trunk: fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (default) or the direct implicit-GEMM kernel")
     ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
@@ -352,6 +353,8 @@ def main():
     else:
         trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=42, conv_dtype=args.conv_dtype, conv_algo=args.conv_algo,
                                        features_roi=args.features_roi)   # same init on every rank
+    if args.wino_waves:
+        trk.vgg.wino_waves = args.wino_waves
     log("tracker built; generating synthetic inputs")
     from ntmtrack import parallel
     lo, hi = parallel.shard_range(world * B, rank, world)          # this rank's sequences of the global batch

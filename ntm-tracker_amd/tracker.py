@@ -323,6 +323,11 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         else:
             plan = self.core._cluster_plan(self.B)
             self.serial_trunk = bool(plan) and 2 * self.B * plan[1] > L.ntk_cu_count()
+        # Beside the HBM-streaming cluster kernels the eight-wave form of the F(4x4) trunk kernel loses what it gains alone
+        # (configs[2]: 110.3 ms per step against 107.8 with round 2's four-wave form; the trunk stream 105.0 against 103.3):
+        # the overlapped trunk keeps the four-wave kernel.
+        if self.vgg is not None and not self.serial_trunk and self.vgg.wino_waves is None:
+            self.vgg.wino_waves = 4
 
     def _flat_grad(self):
         return self.core.params.grad

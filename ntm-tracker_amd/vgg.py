@@ -189,6 +189,8 @@ class VGG16Conv43(object):
         # "winograd2" = fused Winograd F(2x2,3x3) (2.25x fewer multiplies, error ~3e-7 per layer); the direct
         # implicit-GEMM kernel runs where neither applies (conv1_1, odd frame sizes) and everywhere with "direct"
         self.algo = algo
+        # form of the F(4x4) kernel: None = the library's default (eight waves per workgroup); 4 = round 2's one-wave-per-SIMD kernel
+        self.wino_waves = None
         self.packed = {}
         self.packed_wino = {}
         self.packed_wino43 = {}
@@ -234,7 +236,7 @@ class VGG16Conv43(object):
                 if win is not None and out is None:
                     out = torch.zeros((x.shape[0], x.shape[1], x.shape[2], cout), device=x.device, dtype=torch.float32)
                 x = conv3x3_relu_wino43(x, self.packed_wino43[name], b, cin, cout, fuse_pool=(pool and not last),
-                                        out=out if last else None, window=win)
+                                        out=out if last else None, window=win, waves=self.wino_waves)
             elif name in self.packed_wino and wino_supported(cin, cout, x.shape[1], x.shape[2], x.shape[0]):
                 x = conv3x3_relu_wino(x, self.packed_wino[name], b, cin, cout, fuse_pool=(pool and not last),
                                       out=out if last else None)
