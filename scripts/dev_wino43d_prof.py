@@ -22,7 +22,7 @@ n8 = cin // 8
 for wv in range(8):
     v = buf[12 * wv:12 * wv + 12]
     if wv < 4:
-        names = ["-> barrier arrive", "barrier wait", "stage request, transform", "stage store, 24 MFMAs"]
+        names = ["-> barrier arrive", "barrier wait", "previous step's group 1 (8 / 16 MFMAs), stage request, transform", "group 0 (12 MFMAs), stage store, operand requests"]
         idx = [0, 1, 2, 8]
         role = "T " + ("rows 1,2", "rows 3,4", "row 0", "row 5")[wv]
     else:
@@ -32,4 +32,4 @@ for wv in range(8):
     tot = float(sum(v[i] for i in idx))
     print("wave %d (%s): %.0f cycles per K step (x %d); prologue %.0f, loop exit %.0f, epilogue %.0f" % (wv, role, tot / n8, n8, v[6], v[4], v[5]))
     for nm, i in zip(names, idx):
-        print("   %-48s %7.0f  %5.1f %%" % (nm, v[i] / n8, 100.0 * v[i] / tot))
+        print("   %-74s %7.0f  %5.1f %%" % (nm, v[i] / n8, 100.0 * v[i] / tot))

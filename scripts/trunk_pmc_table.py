@@ -1,5 +1,5 @@
-"""Per-layer table of the trunk's PMC passes collected by scripts/profile_r02.sh (gpurun_out/r02p/trunk_pmc/p1..p5) ->
-profiles/r02_vgg_trunk_wino43_hbm_traffic_pmc.csv.  usage: python scripts/trunk_pmc_table.py [root] [out.csv]"""
+"""Per-layer table of the trunk's PMC passes collected by scripts/profile_r02.sh / profile_r03b.sh (<root>/trunk_pmc/p1..p5) ->
+profiles/r02_vgg_trunk_wino43_hbm_traffic_pmc.csv (default).  usage: python scripts/trunk_pmc_table.py [root] [out.csv] [round-note]"""
 import collections
 import csv
 import glob
@@ -47,10 +47,11 @@ spec = [("conv1_1", 224, 3, 64, False), ("conv1_2", 224, 64, 64, True), ("conv2_
 out = open(outp, "w")
 out.write("# rocprofv3 --kernel-trace --pmc <group> (five separate passes: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU |\n")
 out.write("# SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ... | SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY) on `python3 scripts/dev_trunk_pass.py 640 winograd`\n")
-out.write("# (default fp32 trunk of round 2: conv1_1 row kernel + nine fused Winograd F(4x4,3x3) layers, conv_wino43.hip); mean of 6 launches per layer;\n")
-out.write("# collected by scripts/profile_r02.sh, tabulated by scripts/trunk_pmc_table.py.\n")
+note = sys.argv[3] if len(sys.argv) > 3 else "default fp32 trunk of round 2: conv1_1 row kernel + nine fused Winograd F(4x4,3x3) layers, conv_wino43.hip; collected by scripts/profile_r02.sh"
+out.write("# (%s); mean of 6 launches per layer;\n" % note)
+out.write("# tabulated by scripts/trunk_pmc_table.py.\n")
 out.write("# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B requests at 64 B -> doubled; WRITE_SIZE as read. Counter unit KB.\n")
-out.write("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines * 1024 SIMDs): share of SIMD cycles with the fp32 MFMA pipe busy (one wave per SIMD here).\n")
+out.write("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines * 1024 SIMDs): share of SIMD cycles with the fp32 MFMA pipe busy.\n")
 out.write("# lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; parked / issue_stall / issuing = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES.\n")
 out.write("layer,fetch_bytes(FETCH_SIZE*1024*2),write_bytes(WRITE_SIZE*1024),algorithmic_bytes(in+weights+out),traffic/algorithmic,mfma_busy,valu_per_mfma,lds_conflict,parked,issue_stall,issuing\n")
 tf = tw = ta = 0
