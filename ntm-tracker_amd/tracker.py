@@ -129,15 +129,18 @@ class _TwoStreamPipeline(object):
         self._pending = []
         self._next_slot = 0
         self._proj_done = None      # event: input projection of the batch being trained is enqueued/done
-        self.trunk_waits_for_projection = os.environ.get("NTK_TRUNK_WAITS_FOR_PROJECTION", "0") != "0"
+        self.trunk_waits_for_projection = os.environ.get("NTK_TRUNK_WAITS_FOR_PROJECTION", "1") != "0"
 
     def _mark_projection(self):
         """Called by the core's forward pass right after the input-projection GEMM.  With
-        `trunk_waits_for_projection` (NTK_TRUNK_WAITS_FOR_PROJECTION=1; round 1's default) the next trunk pass waits
-        for this point, so the projection at the head of the serial recurrent chain runs on an idle chip instead of
-        queueing behind conv1_1 of the next batch.  Since round 2 the chain has slack against the trunk (it is the
-        trunk stream that bounds a step) and the 0.5 ms the trunk stream idled there cost more than the projection
-        gains: measured 64.62 -> 64.51 ms per step (configs[1]), 125.7 -> 124.2 ms (configs[2]); default off."""
+        `trunk_waits_for_projection` (the default; NTK_TRUNK_WAITS_FOR_PROJECTION=0 turns it off) the next trunk pass waits
+        for this point, so the tail of the serial recurrent chain -- weight-gradient GEMMs, optimiser, gather, the input
+        projection -- runs on an idle chip instead of queueing behind the first layers of the next trunk pass (stream
+        priority does not help: a trunk workgroup holds its CU until it exits).  Which way this pays depends on which
+        stream bounds the step: round 1 had it on; round 2 off (the trunk stream was the bound and the 0.5 ms it idled
+        cost more than the projection gained: 64.62 -> 64.51 ms per step); since round 3's trunk kernel the recurrent
+        chain is the bound and it is on again: configs[1] 58.14 -> 57.26 ms per step (the projection 2.1 -> 0.39 ms, the
+        gather 0.43 -> 0.03), configs[2] unchanged (107.7 -> 107.6: its trunk pass ends inside that tail either way)."""
         if self._s_ntm is not None:
             self._proj_done = torch.cuda.Event()
             self._proj_done.record(torch.cuda.current_stream(self.device))
