@@ -502,10 +502,12 @@ class DNC(object):
         gemm_tn(rec["hc"].view(BS, self.ldh), dxi.view(BS, self.IP), P.view("Wi", grad=True), accumulate=accumulate)
         gemm_tn(rec["yin"].view(BS, self.ldy), dypre.view(BS, self.OP), P.view("Wy", grad=True), accumulate=accumulate)
 
-    def backward_sequence(self, X, dout):
+    def backward_sequence(self, X, dout, unpack=True):
         """BPTT through the last recorded sequence (run_projected(..., record=True)).
         X [B,S,ldx] serialised inputs, dout [B,S,O] = d loss / d output.  Returns the gradients in the
-        reference's Sonnet variable layout ({name: tensor on device}).  When the forward pass was segmented
+        reference's Sonnet variable layout ({name: tensor on device}) -- or nothing with unpack=False: the gradients are in
+        `params.grad` (packed kernel layout) either way, which is all a training step reads; the re-layout is a dozen small
+        launches at the tail of the serial chain (1.3 ms of configs[2]'s step).  When the forward pass was segmented
         (see record_budget_bytes) each segment is re-recorded from its checkpoint, last segment first; the
         state gradients flow between segments through gM / gL / gcarry."""
         if not 1 <= self.Wn <= 4:
@@ -527,7 +529,7 @@ class DNC(object):
         if not self.last_segments:
             dgates, dxi, dypre = self._launch_bwd(B, S, st0, rec, dout, WrT, ldkT, WiT, ldhT, gM, gL, None, False)
             self._weight_grads(X.view(B * S, self.ldx), rec, dgates, dxi, dypre, B * S, False)
-            return self._unpack(grad=True)
+            return self._unpack(grad=True) if unpack else None
         xp, ckpt, bounds, fwd_recs, seg_cap = self.last_segments
         nseg = len(bounds)
         gcarry = torch.zeros((B, (self.Wn + 1) * self.N + self.R * self.N + ldkT + hid), device=dev)
@@ -573,7 +575,7 @@ class DNC(object):
             self._weight_grads(X[:, s0:s1].contiguous().view(B * n, self.ldx), rec, dgates, dxi, dypre, B * n, not first)
             first = False
             del rec                                                # freed in this stream's order: after its last reader
-        return self._unpack(grad=True)
+        return self._unpack(grad=True) if unpack else None
 
     def __call__(self, inputs, prev_state):
         """One step of the core: (output [B,O], DNCState), dnc.py:84-127."""

@@ -354,7 +354,7 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def loss_and_grads(self, fmap, gts0, offsets):
         logits, _state = self.forward_features(fmap, gts0, record=True)
         loss, pred, dlogits = offset_loss(logits, offsets, self.T)
-        self.core.backward_sequence(self._X, dlogits)
+        self.core.backward_sequence(self._X, dlogits, unpack=False)      # the optimiser reads params.grad (packed layout)
         # a cluster launch that aborted (a hand-off timed out) must not feed the optimiser: loss -> NaN, gradient -> 0, on the
         # device, without a synchronisation; DNC.check_cluster() raises where the caller next synchronises
         self.core.guard(loss, self.core.params.grad)
