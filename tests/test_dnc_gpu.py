@@ -273,6 +273,13 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, W
         if err > max(1e-4, 3 * err32):
             bad[k] = (err, err32)
     print("%s/%s relative gradient error (HIP, float32 oracle) vs float64: %s" % (name, form, {k: ("%.1e" % a, "%.1e" % b) for k, (a, b) in worst.items()}))
+    # the training step's form: no re-layout, nothing returned, the same gradients in params.grad (packed layout; its padding is
+    # not defined, so the comparison goes through the re-layout)
+    core.run_sequence(torch.from_numpy(x).to(cuda), gst, record=True)
+    assert core.backward_sequence(core.last_X, dout, unpack=False) is None
+    again = core._unpack(grad=True)
+    for k in grads:      # (the one-workgroup kernels' reductions are not fixed-order: equal to rounding, not to the bit)
+        assert float((again[k] - grads[k]).abs().max()) <= 1e-5 * float(grads[k].abs().max()) + 1e-12, k
     assert not bad, bad
 
 
