@@ -19,7 +19,6 @@
 // 128 VGPRs, 32 KB LDS, FOUR workgroups per CU: 132-133 TFLOP/s.  The default trunk is the Winograd kernel
 // (conv_wino.hip); this file serves algo="direct", tiny-Cin / odd shapes and the plain GEMMs around the recurrence.
 #include "common.h"
-#include <cstdlib>
 #include "conv_common.h"
 
 namespace {
@@ -694,8 +693,8 @@ extern "C" int ntk_vgg_conv3x3_relu_f32(const float* in, const float* w_packed, 
     if (cin == 3 && cout == 64 && !fuse_pool && (W % 32) == 0) {
         const long nseg = (long)frames * H * (W / 32);
         NTK_REQUIRE(nseg < 2147483647L, NTK_ERR_BAD_SHAPE, "ntk_vgg_conv3x3_relu_f32: %ld row segments", nseg);
-        static const long c11_wgs = [] { const char* e = getenv("NTK_C11_WGS"); return e ? atol(e) : 1024L; }();     // dev switch
-        const int wgs = (int)((nseg + 3) / 4 < c11_wgs ? (nseg + 3) / 4 : c11_wgs);      // waves stride over segments
+        // 256 CUs x 4 workgroups, waves stride over segments (4 096 / 16 384 shorter-lived workgroups measured the same, alone and in the step)
+        const int wgs = (int)((nseg + 3) / 4 < 1024 ? (nseg + 3) / 4 : 1024);
         conv_c3_rows_kernel<false><<<wgs, 256, 0, st>>>(in, w_packed, bias, out, (int)nseg, H, W);
     } else if (smallc) {
         if (bn128) launch_conv<128, true>(in, w_packed, bias, out, npatch, H, W, cin, cout, Kp, fuse_pool, st);
