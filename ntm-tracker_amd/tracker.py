@@ -140,7 +140,8 @@ class _TwoStreamPipeline(object):
         stream bounds the step: round 1 had it on; round 2 off (the trunk stream was the bound and the 0.5 ms it idled
         cost more than the projection gained: 64.62 -> 64.51 ms per step); since round 3's trunk kernel the recurrent
         chain is the bound and it is on again: configs[1] 58.14 -> 57.26 ms per step (the projection 2.1 -> 0.39 ms, the
-        gather 0.43 -> 0.03), configs[2] unchanged (107.7 -> 107.6: its trunk pass ends inside that tail either way)."""
+        gather 0.43 -> 0.03); configs[2] 107.7 -> 107.6 with the four-wave trunk kernel but 110.8 -> 104.6 with the eight-wave one,
+        which is what its tracker runs when the trunk waits (DNCOffsetTracker)."""
         if self._s_ntm is not None:
             self._proj_done = torch.cuda.Event()
             self._proj_done.record(torch.cuda.current_stream(self.device))
@@ -326,10 +327,11 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         else:
             plan = self.core._cluster_plan(self.B)
             self.serial_trunk = bool(plan) and 2 * self.B * plan[1] > L.ntk_cu_count()
-        # Beside the HBM-streaming cluster kernels the eight-wave form of the F(4x4) trunk kernel loses what it gains alone
-        # (configs[2]: 110.3 ms per step against 107.8 with round 2's four-wave form; the trunk stream 105.0 against 103.3):
-        # the overlapped trunk keeps the four-wave kernel.
-        if self.vgg is not None and not self.serial_trunk and self.vgg.wino_waves is None:
+        # The eight-wave form of the F(4x4) trunk kernel beside the HBM-streaming cluster kernels (configs[2], ms per step): with the
+        # next trunk pass waiting for the input projection (the default) 104.6 against 107.8 with round 2's four-wave form; WITHOUT
+        # that wait it loses what it gains alone (110.8 against 107.7: its workgroups then sit on the CUs the chain's tail is
+        # queueing for), so a tracker whose trunk does not wait keeps the four-wave kernel.
+        if self.vgg is not None and not self.serial_trunk and not self.trunk_waits_for_projection and self.vgg.wino_waves is None:
             self.vgg.wino_waves = 4
 
     def _flat_grad(self):
