@@ -43,7 +43,7 @@ __device__ unsigned long long g_w43_prof[4][24];
 
 // Ablation switches for scripts/dev_wino_variant.sh (results are WRONG with any of them set; never defined in the product
 // build): bit 0 no U loads in the K loop, bit 1 no input transform, bit 2 no patch staging, bit 3 no workgroup barrier in
-// the K loop, bit 4 no A-operand reads.
+// the K loop, bit 4 no A-operand reads, bit 5 (eight-wave kernel) contiguous staging addresses.
 #ifndef W43_ABL
 #define W43_ABL 0
 #endif
@@ -689,6 +689,9 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W)
                     soff[k] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + c4 * 4) * sizeof(float));
             }
+            // ablation bit 5 (timing only, results wrong): the slots of a patch read CONTIGUOUS 16-byte pieces -- what a channel-blocked
+            // activation layout [C/8][H][W][8] would give the staging loads (an upper bound: also drops the halo overlap between patches)
+            if constexpr ((W43_ABL & 32) != 0) soff[k] = (unsigned)(stid + k * 256) * 16u;
             if constexpr (PACK) soff[k] = (soff[k] == W43_OOB ? 0xfffff000u : (soff[k] >> 4) << 12) | (unsigned)dst[k];
         }
     };
