@@ -618,7 +618,7 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pg = wave & 3, nbw = wave >> 2;                          // plane group (= SIMD), 32-channel half
+    const int pg = wave & 3;                                           // plane group (= SIMD)
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     int cb, sp;
     if (a.nCB >= 8) {
@@ -714,6 +714,82 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto load_plane = [&](const float* vcur, int j) {
         if constexpr ((W43_ABL & 16) != 0) return f32x4{1.f, 1.f, 1.f, 1.f};
         else return *reinterpret_cast<const f32x4*>(vcur + j * 256);
+    };
+    // ---- epilogue pieces (called from the role branches: a branch then carries only its own accumulators through them).  One
+    // 32-channel half at a time through LDS: half 0 sits in the T waves (planes 0..4 / 0..5 and an adopted one) and the S waves
+    // (planes 6..8) and is transformed by the T waves, whose accumulators are dead by then (the S waves still hold half 1);
+    // half 1 by the S waves.  thread = (tile, four adjacent channels)
+    float* sZ = s_mem;
+    const int col = lane & 31;
+    auto z_store = [&](const f32x16& v, int plane) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
+            sZ[((9 * pg + plane) * 32 + m) * 32 + col] = v[r];
+        }
+    };
+    auto out_transform = [&](auto nb_c) {
+        constexpr int nb = decltype(nb_c)::value;
+        const int et = tid & 255;
+        const int m = et >> 3, cq = et & 7;
+        const int n = 64 * cb + 32 * nb + 4 * cq;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+        const int mq = m / STILE, ml = m - mq * STILE;
+        const int f = s_sbf[mq];
+        if (f >= 0) {
+            const f32x4* zp = reinterpret_cast<const f32x4*>(sZ + m * 32 + 4 * cq);
+            f32x4 z[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x4 mm[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) mm[i] = zp[(i * 6 + j) * 256];
+                const f32x4 s12 = mm[1] + mm[2], d12 = mm[1] - mm[2], s34 = mm[3] + mm[4], d34 = mm[3] - mm[4];
+                z[0][j] = mm[0] + s12 + s34;
+                z[1][j] = d12 + 2.f * d34;
+                z[2][j] = s12 + 4.f * s34;
+                z[3][j] = d12 + 8.f * d34 + mm[5];
+            }
+            f32x4 y[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 s12 = z[k][1] + z[k][2], d12 = z[k][1] - z[k][2], s34 = z[k][3] + z[k][4], d34 = z[k][3] - z[k][4];
+                y[k][0] = z[k][0] + s12 + s34;
+                y[k][1] = d12 + 2.f * d34;
+                y[k][2] = s12 + 4.f * s34;
+                y[k][3] = d12 + 8.f * d34 + z[k][5];
+            }
+            const int tr = ml / TW, tc = ml - tr * TW;
+            const int oy = s_sby[mq] + 4 * tr, ox = s_sbx[mq] + 4 * tc;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (POOL) {
+                float* op = a.out + (((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n;
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = fmaxf(fmaxf(y[2 * aa][2 * b][e], y[2 * aa][2 * b + 1][e]), fmaxf(y[2 * aa + 1][2 * b][e], y[2 * aa + 1][2 * b + 1][e]));
+                        v = v + bv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
+                        W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * (W >> 1) + b) * Cout), v);
+                    }
+            } else {
+                float* op = a.out + (((size_t)f * H + oy) * W + ox) * Cout + n;
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        f32x4 v = y[aa][b] + bv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
+                        W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * W + b) * Cout), v);
+                    }
+            }
+        }
     };
 #define W43D_MFMA(C, A, B) C = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0)
 
@@ -893,6 +969,20 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int u = 0; u < NG1; ++u) W43D_MFMA(acc[3 + u], As[u][q], Bq1[u][q]);
+            // ---- epilogue, T side (four barriers, as on the S side)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                         // (E0) every wave has left the K loop: the Z image may overwrite raw / V
+            W43_STAMP(4);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) z_store(acc[j], j);
+            if constexpr (!HEAVY) {
+                z_store(acc[5], 5);
+                z_store(acc[6], 5 - 18);                             // plane 5 of wave pg - 2
+            }
+            __syncthreads();                                         // (E1) half 0 is in LDS
+            out_transform(ic<0>{});
+            __syncthreads();                                         // (E2) half 0 has been read
+            __syncthreads();                                         // (E3) half 1 is in LDS (S waves)
         };
         if (wave == 0) t_loop(ic<0>{});
         else if (wave == 1) t_loop(ic<1>{});
@@ -948,107 +1038,23 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             s_step(c8, ic<0>{});
             s_step(c8 + 1, ic<1>{});
         }
+        // ---- epilogue, S side
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                             // (E0)
+        W43_STAMP(4);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) z_store(acc[4 * g + 3], 6 + g);
+        __syncthreads();                                             // (E1)
+        __syncthreads();                                             // (E2) half 0 has been read by the T waves
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) z_store(acc[4 * g + pl], 3 * g + pl);
+        __syncthreads();                                             // (E3)
+        out_transform(ic<1>{});
     }
 #undef W43D_MFMA
 
-    // ---- epilogue: one 32-channel half at a time through LDS.  Half 0 sits in the T waves (planes 0..5 of their nine) and the S
-    // waves (planes 6..8); its output transform is run by the T waves, whose accumulators are dead by then (the S waves still hold
-    // half 1); half 1's by the S waves.  thread = (tile, four adjacent channels)
-    float* sZ = s_mem;
-    const int col = lane & 31;
-    W43_STAMP(4);
-    auto z_store = [&](const f32x16& v, int plane) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = 4 * kh + (r & 3) + 8 * (r >> 2);
-            sZ[((9 * pg + plane) * 32 + m) * 32 + col] = v[r];
-        }
-    };
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        __syncthreads();
-        if (nb == 0) {
-            if (nbw == 0) {                                          // T waves: planes 0..4 (+ 5, + plane 5 of wave pg - 2)
-#pragma unroll
-                for (int j = 0; j < 5; ++j) z_store(acc[j], j);
-                if (pg >= 2) {
-                    z_store(acc[5], 5);
-                    z_store(acc[6], 5 - 18);
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) z_store(acc[4 * g + 3], 6 + g);
-            }
-        } else if (nbw == 1) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) z_store(acc[4 * g + pl], 3 * g + pl);
-        }
-        __syncthreads();
-        if (nbw == nb) {
-            const int et = tid & 255;
-            const int m = et >> 3, cq = et & 7;
-            const int n = 64 * cb + 32 * nb + 4 * cq;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-            const int mq = m / STILE, ml = m - mq * STILE;
-            const int f = s_sbf[mq];
-            if (f >= 0) {
-                const f32x4* zp = reinterpret_cast<const f32x4*>(sZ + m * 32 + 4 * cq);
-                f32x4 z[4][6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    f32x4 mm[6];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) mm[i] = zp[(i * 6 + j) * 256];
-                    const f32x4 s12 = mm[1] + mm[2], d12 = mm[1] - mm[2], s34 = mm[3] + mm[4], d34 = mm[3] - mm[4];
-                    z[0][j] = mm[0] + s12 + s34;
-                    z[1][j] = d12 + 2.f * d34;
-                    z[2][j] = s12 + 4.f * s34;
-                    z[3][j] = d12 + 8.f * d34 + mm[5];
-                }
-                f32x4 y[4][4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4 s12 = z[k][1] + z[k][2], d12 = z[k][1] - z[k][2], s34 = z[k][3] + z[k][4], d34 = z[k][3] - z[k][4];
-                    y[k][0] = z[k][0] + s12 + s34;
-                    y[k][1] = d12 + 2.f * d34;
-                    y[k][2] = s12 + 4.f * s34;
-                    y[k][3] = d12 + 8.f * d34 + z[k][5];
-                }
-                const int tr = ml / TW, tc = ml - tr * TW;
-                const int oy = s_sby[mq] + 4 * tr, ox = s_sbx[mq] + 4 * tc;
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (POOL) {
-                    float* op = a.out + (((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n;
-#pragma unroll
-                    for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                v[e] = fmaxf(fmaxf(y[2 * aa][2 * b][e], y[2 * aa][2 * b + 1][e]), fmaxf(y[2 * aa + 1][2 * b][e], y[2 * aa + 1][2 * b + 1][e]));
-                            v = v + bv;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
-                            W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * (W >> 1) + b) * Cout), v);
-                        }
-                } else {
-                    float* op = a.out + (((size_t)f * H + oy) * W + ox) * Cout + n;
-#pragma unroll
-                    for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            f32x4 v = y[aa][b] + bv;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
-                            W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * W + b) * Cout), v);
-                        }
-                }
-            }
-        }
-    }
 #ifdef NTK_CL_PROF
     W43_STAMP(5);
     if (prof_on)
