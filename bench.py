@@ -28,7 +28,7 @@ import torch
 # counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv
 # (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
-TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": 8.9765e10 + 2.6133e10}
+TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": 8.7996e10 + 2.3872e10}
 TRUNK_TRAFFIC_PROFILE = {"direct": "profiles/r01_vgg_trunk_hbm_traffic_pmc.csv", "winograd2": "profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv",
                          "winograd": "profiles/r03_vgg_trunk_wino43d_hbm_traffic_pmc.csv"}
 # fraction of the direct-convolution multiplies the Winograd layers execute on the MFMA pipe: F(2x2,3x3) 16 per 2x2 tile
