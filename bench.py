@@ -433,6 +433,12 @@ def main():
         frames_total = world * B * T * args.steps
         vgg_ms = float(np.mean([a.elapsed_time(b) for a, b in marks_vgg]))
         ntm_ms = float(np.mean([a.elapsed_time(b) for a, b in marks_ntm])) if marks_ntm else 0.0
+        ends = [m[1] for m in marks_ntm]
+        steady_ms = round(float(np.median([ends[i].elapsed_time(ends[i + 1]) for i in range(len(ends) - 1)])), 3) if len(ends) >= 4 else None
+        if len(ends) >= 2:
+            log("core pass end-to-end intervals (ms): %s; first core pass %.2f ms, first trunk pass %.2f ms" % (
+                " ".join("%.2f" % ends[i].elapsed_time(ends[i + 1]) for i in range(len(ends) - 1)),
+                marks_ntm[0][0].elapsed_time(marks_ntm[0][1]), marks_vgg[0][0].elapsed_time(marks_vgg[0][1])))
         flops = conv_flops_per_frame() * B * T
         algorithmic = flops / (vgg_ms * 1e-3) / 1e12
         # executed MFMA flops: conv1_1 runs the direct kernel; the nine Winograd layers execute a fixed fraction of the
@@ -485,7 +491,10 @@ def main():
                                  % (WINO_EXECUTED_FRACTION[args.conv_algo], getattr(trk.vgg, "split_streams", 1))
                                  if wino else "direct convolution: executed = algorithmic flops"},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
-                             "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times"},
+                             "steady_state_step": steady_ms,
+                             "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times; steady_state_step = median interval "
+                                     "between the ends of consecutive core passes (ms_per_step also carries the pipeline's fill and drain: "
+                                     "the first trunk pass and the last core pass of the K timed steps run alone)"},
         }
         out["memory_step"], out["memory_step_bptt"] = memory_step_probe(trk, args.model, gts0, offs, B, T)
         if not args.no_cpu_baseline and world == 1:
