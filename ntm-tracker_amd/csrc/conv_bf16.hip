@@ -9,6 +9,12 @@
 #include "common.h"
 #include "conv_common.h"
 
+// Ablation switches for scripts/dev_wino_variant.sh (timing only; never defined in the product build): bit 0 no global -> LDS
+// staging after the first K-tile, bit 1 no MFMAs, bit 2 no barriers in the K loop, bit 3 no output stores.
+#ifndef BF16_ABL
+#define BF16_ABL 0
+#endif
+
 namespace {
 
 constexpr int BM = 128;
@@ -107,7 +113,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_relu_bf16_dma_kernel(
         const int chunk = kt / 9, tap = kt - chunk * 9;
         const int c0 = chunk * BKB;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        if (kt > 0) __syncthreads();
+        if ((BF16_ABL & 4) == 0 && kt > 0) __syncthreads();
+        if ((BF16_ABL & 1) == 0 || kt == 0) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int yy = ry[jj] + dy, xx = rx[jj] + dx;
@@ -118,9 +125,10 @@ __global__ __launch_bounds__(256, 4) void conv3x3_relu_bf16_dma_kernel(
         }
 #pragma unroll
         for (int jj = 0; jj < NBI; ++jj) lds_dma16b(bsrc[jj] + kt * BKB, Bs + (wave * NBI + jj) * 8 * 32);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        mma_ktile_bf16_swz<BN>(As, Bs, acc, wm, wn, lane);
+        if ((BF16_ABL & 4) == 0) __syncthreads();
+        if ((BF16_ABL & 2) == 0) mma_ktile_bf16_swz<BN>(As, Bs, acc, wm, wn, lane);
     }
 
     const int kh = lane >> 5, col = lane & 31;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_relu_bf16_dma_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pix = s_pix[mbase + (r & 3) + 8 * (r >> 2)];
-                    if (pix >= 0) {
+                    if (pix >= 0 && ((BF16_ABL & 8) == 0 || acc[tm][tn][r] == 12345.f)) {
                         const float v = fmaxf(acc[tm][tn][r] + bv, 0.f);
                         if constexpr (OUTF32) reinterpret_cast<float*>(outv)[(size_t)pix * Cout + n] = v;
                         else reinterpret_cast<__bf16*>(outv)[(size_t)pix * Cout + n] = (__bf16)v;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_relu_bf16_dma_kernel(
                     const int pp = s_ppix[mbase + 8 * g];
                     const float v = fmaxf(fmaxf(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1]),
                                           fmaxf(acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
-                    if (pp >= 0) {
+                    if (pp >= 0 && ((BF16_ABL & 8) == 0 || v == 12345.f)) {
                         const float o = fmaxf(v + bv, 0.f);
                         if constexpr (OUTF32) reinterpret_cast<float*>(outv)[(size_t)pp * Cout + n] = o;
                         else reinterpret_cast<__bf16*>(outv)[(size_t)pp * Cout + n] = (__bf16)o;
