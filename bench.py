@@ -295,6 +295,33 @@ def memory_step_probe(trk, model, gts0, offs, B, T):
     return fwd, entry(kern_b, ms_b, traffic_b)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks ourselves, as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>`), pass its stdout (rank 0's one JSON line) and stderr through, and return its exit code.  This process has
+    made no GPU call at this point (importing torch does not initialise HIP) and never replaces itself: no os.exec*."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("--gpus %d without WORLD_SIZE: launching %d ranks as a child process: %s" % (n, n, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
+def trunk_alone_probe(trk, frames):
+    """The trunk pass alone on an idle device (outside the timed region; HIP events on the current stream, median of 3)."""
+    torch.cuda.synchronize()
+    return _median_ms(lambda: trk.vgg(frames, out=trk._slots[0]["buf"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +345,8 @@ def main():
     ap.add_argument("--mem-dim", type=int, default=None)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -422,6 +451,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if args.mode == "train":
+        trk.check_step()        # raises (non-zero exit) if a cluster launch aborted or an optimiser step was skipped on a non-finite gradient
     log("timed %d steps in %.3f s; peak device memory allocated %.1f GB, reserved %.1f GB" % (
         args.steps, elapsed, torch.cuda.max_memory_allocated(dev) / 1e9, torch.cuda.max_memory_reserved(dev) / 1e9))
     if dist is not None:
@@ -470,13 +501,16 @@ def main():
                        **({"features_roi": "conv4_3 computed in the 25 of 49 output tiles extract_features reads (optional; the flops "
                                            "in `roofline` are reduced accordingly; NOT the headline configuration)"}
                           if (args.features_roi and getattr(trk, "features_roi", False)) else {})},
-            "roofline": {"bound": "mfma", "kernel": (("conv3x3_wino43d_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(4x4,3x3) layers)"
+            "roofline": {"bound": "mfma", "kernel": ((("conv3x3_wino43d_kernel" if trk.vgg.wino_waves in (None, 8) else "conv3x3_wino43_kernel (four-wave form)")
+                                                      + " (VGG trunk: conv1_1 direct + 9 fused Winograd F(4x4,3x3) layers; a 1x1x32-block layer"
+                                                        " whose blocks span more than 16 MB of input falls back to the four-wave form)"
                                                       if args.conv_algo == "winograd" else
                                                       ("conv3x3_wino_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(2x2,3x3) layers)"
                                                        if args.conv_algo == "winograd2" else "conv3x3_relu_dma_kernel (VGG trunk, 10 layers)"))
                                                      if args.conv_dtype == "f32" else "conv3x3_relu_bf16_kernel (VGG trunk, 10 layers)"),
                          "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4),
+                         "frac_algorithmic": round(algorithmic / PEAK, 4),
                          "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo] * (B * T) / 640.0)
                          if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo]) else None,
                          "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (%s), scaled by frames/640; algorithmic 4.563e10 B per 640 frames" % TRUNK_TRAFFIC_PROFILE[args.conv_algo],
@@ -485,7 +519,9 @@ def main():
                          "algorithmic_tflops": round(algorithmic, 2),
                          "note": ("achieved / frac = EXECUTED MFMA flops (conv1_1 direct + %.4f of the direct-convolution count for the "
                                   "nine Winograd layers) / trunk time measured with HIP events on the trunk's stream inside the timed "
-                                  "region; algorithmic_tflops = the direct-convolution count (SURVEY 8d: 27.92 GFLOP/frame) / the same time"
+                                  "region; algorithmic_tflops / frac_algorithmic = the direct-convolution count (SURVEY 8d: 27.92 GFLOP/frame) / "
+                                  "the same time (/ peak: above 1 because F(4x4,3x3) executes a quarter of the direct form's multiplies, "
+                                  "not because work is skipped)"
                                   "; the trunk pass runs as %d stream part(s): with 2, kernel durations in a rocprof --stats summary overlap "
                                   "pairwise (scripts/trace_union.py gives the union of their intervals per pass)")
                                  % (WINO_EXECUTED_FRACTION[args.conv_algo], getattr(trk.vgg, "split_streams", 1))
@@ -496,7 +532,25 @@ def main():
                                      "between the ends of consecutive core passes (ms_per_step also carries the pipeline's fill and drain: "
                                      "the first trunk pass and the last core pass of the K timed steps run alone)"},
         }
+        if args.model == "dnc":
+            ch = getattr(trk, "cluster_choice", None)
+            out["config"]["cluster_choice"] = ("%s, k = %d (constructor's choice for a step with a trunk to overlap)" % ch) if ch else "core's automatic choice"
         out["memory_step"], out["memory_step_bptt"] = memory_step_probe(trk, args.model, gts0, offs, B, T)
+        # The step is bound by total CU-time once both streams are busy: the trunk's workgroups fill whatever CUs the
+        # persistent core workgroups (one per sequence; B * k for the DNC cluster forms) do not hold.
+        from ntmtrack import _lib as L_
+        cus = int(L_.lib().ntk_cu_count())
+        trunk_alone = trunk_alone_probe(trk, frames)
+        core_wgs = B * (getattr(trk.core, "last_cluster_k", 1) if args.model == "dnc" else 1)
+        core_ms = ntm_ms if ntm_ms else out["memory_step"]["ms"]
+        cu_trunk, cu_core = trunk_alone * 1e-3 * cus, core_ms * 1e-3 * min(core_wgs, cus)
+        out["breakdown_ms"]["trunk_alone"] = round(trunk_alone, 3)
+        out["breakdown_ms"]["cu_seconds"] = {
+            "trunk": round(cu_trunk, 3), "core": round(cu_core, 3), "compute_units": cus, "core_workgroups": core_wgs,
+            "cu_time_bound_ms": round((cu_trunk + cu_core) / cus * 1e3, 3),
+            "note": "trunk = the trunk pass alone on the idle device x every CU (its grids fill the chip); core = the core pass of the "
+                    "timed region (serialise .. optimiser; the persistent recurrent kernels are all but ~3 ms of it) x the CUs its "
+                    "persistent workgroups hold; cu_time_bound_ms = (trunk + core) / CUs: what the step cannot beat while both streams overlap"}
         if not args.no_cpu_baseline and world == 1:
             # the DNC restatement costs ~15 ms per step on the host: a 4-frame sequence keeps the sample inside its time budget
             out["cpu_baseline"] = cpu_baseline(ws, T=20 if args.model == "ntm" else 4, model=args.model,

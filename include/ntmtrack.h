@@ -270,10 +270,13 @@ int ntk_dnc_cluster_status(const void* workspace, int B, int k, void* stream);
 int ntk_dnc_cluster_placement(const void* workspace, int B, int k, int* same_xcd_clusters, void* stream);
 /* Device-side propagation of an aborted cluster launch, without a host synchronisation: when the sticky error word of
  * `workspace` (either form: mp_form 0 = ntk_dnc_cluster_*, 1 = ntk_dnc_mp_*, with its workspace_bytes) is set, loss[0]
- * becomes NaN and grad[0..n) zero, so that the optimiser step enqueued behind it is harmless and the failure is visible
- * to whoever reads the loss.  loss / grad may be null. */
+ * and grad[0..n) become NaN: the NaN survives the data-parallel SUM all-reduce, so EVERY rank sees a NaN global norm and
+ * ntk_rmsprop_clip_step_checked skips the update everywhere (zeros would have let the other ranks step on a partial
+ * gradient).  loss / grad may be null.  ntk_dnc_cluster_inject_abort sets that sticky word the way a timed-out hand-off
+ * does (fault injection for tests). */
 int ntk_dnc_cluster_guard(const void* workspace, size_t workspace_bytes, int mp_form, int B, int k, float* loss, float* grad,
                           size_t n, void* stream);
+int ntk_dnc_cluster_inject_abort(void* workspace, size_t workspace_bytes, int mp_form, int B, int k, void* stream);
 int ntk_dnc_cluster_fwd(int B, int S, int N, int W, int R, int Wn, int hid, int O, float clip_value, int k,
                         const float* xproj, const float* Wr, const float* Wi, const float* Wy,
                         float* mem, float* link, float* usage, float* rw, float* ww, float* prec,
@@ -311,6 +314,10 @@ int ntk_dnc_cluster_bwd(int B, int S, int N, int W, int R, int Wn, int hid, int 
  * owner: besides the per-launch control words (re-zeroed by every launch) its last 256-byte line holds a STICKY error
  * word that a timed-out hand-off sets and no launch clears.  ntk_dnc_mp_status synchronises `stream` and fails when the
  * last launch or (sticky word) any launch since the word was last cleared aborted; clear_sticky != 0 clears it. */
+/* Compute units the cooperative kernels may count on for the current device: hipDeviceAttributeMultiprocessorCount (assumes
+ * the process has the device to itself -- a CU mask or another process's kernels are invisible to it), capped by the
+ * environment variable NTK_DNC_CU_BUDGET when set; 0 when the device cannot be queried (the cluster forms are then refused
+ * by every planner and the one-workgroup-per-sequence kernels run). */
 int ntk_cu_count(void);
 int ntk_dnc_mp_plan(int B, int N, int W, int R, int Wn, int hid, int O, int k_request, int* k, size_t* workspace_bytes);
 /* > 0 when (shape, k) has a compile-time instantiation of the mp kernels (the generic one is functional but several times slower) */
@@ -485,6 +492,14 @@ int ntk_global_norm(const float* grads, size_t n, float* workspace, float* gnorm
 int ntk_rmsprop_clip_step(float* params, const float* grads, float* ms, float* mom, size_t n,
                           float lr, float decay, float momentum, float eps, float clip_norm,
                           const float* gnorm, void* stream);
+/* The same update behind a finiteness check of *gnorm (required): when the global norm is NaN or Inf -- a poisoned
+ * gradient (ntk_dnc_cluster_guard), on ANY data-parallel rank once the SUM all-reduce has run -- parameters and slots
+ * stay untouched, loss[0] (nullable) becomes NaN and *skipped (nullable, device counter) is incremented; otherwise it is
+ * ntk_rmsprop_clip_step bit for bit.  What the trackers' training steps run (the reference has no failure path here:
+ * tf.clip_by_global_norm would write NaN into every variable). */
+int ntk_rmsprop_clip_step_checked(float* params, const float* grads, float* ms, float* mom, size_t n,
+                                  float lr, float decay, float momentum, float eps, float clip_norm,
+                                  const float* gnorm, float* loss, unsigned* skipped, void* stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,7 @@ def _sig(lib):
         "ntk_dnc_cluster_status": (c_int, [P, c_int, c_int, P]),
         "ntk_dnc_cluster_placement": (c_int, [P, c_int, c_int, P, P]),
         "ntk_dnc_cluster_guard": (c_int, [P, c_size_t, c_int, c_int, c_int, P, P, c_size_t, P]),
+        "ntk_dnc_cluster_inject_abort": (c_int, [P, c_size_t, c_int, c_int, c_int, P]),
         "ntk_dnc_cluster_fwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P] * 13 + [P] * 18 + [P, P]),
         "ntk_dnc_cluster_bwd_plan": (c_int, [c_int] * 8 + [ctypes.POINTER(c_int), ctypes.POINTER(c_size_t)]),
         "ntk_dnc_cluster_bwd": (c_int, [c_int] * 8 + [ctypes.c_float, c_int] + [P, c_int, P, P] + [P] * 7 + [P] * 15 + [P] * 6 + [P, c_int, P, P]),
@@ -103,6 +104,7 @@ def _sig(lib):
         "ntk_global_norm_workspace_bytes": (c_size_t, [c_size_t]),
         "ntk_global_norm": (c_int, [P, c_size_t, P, P, P]),
         "ntk_rmsprop_clip_step": (c_int, [P, P, P, P, c_size_t] + [ctypes.c_float] * 5 + [P, P]),
+        "ntk_rmsprop_clip_step_checked": (c_int, [P, P, P, P, c_size_t] + [ctypes.c_float] * 5 + [P, P, P, P]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: fail loudly

@@ -16,18 +16,32 @@ void ntk_set_error(const char* fmt, ...) {
 extern "C" int ntk_version(void) { return 100; }
 extern "C" const char* ntk_last_error(void) { return g_err; }
 
-// Compute units of the current device (hipDeviceAttributeMultiprocessorCount), cached per device: the cluster kernels
-// need all their workgroups co-resident, one per CU, so their planners cap B * k at THIS number -- a partitioned
-// (CPX / DPX) or smaller device gets a smaller k or the one-workgroup-per-sequence kernels, never a grid that cannot
-// be resident.  256 (the MI355X in SPX mode) when no device can be queried: a launch would fail there anyway.
+// Compute units the cooperative (cluster) kernels may count on, cached per device: those kernels need all their workgroups
+// co-resident, one per CU, so their planners cap B * k at THIS number -- a partitioned (CPX / DPX) or smaller device gets a
+// smaller k or the one-workgroup-per-sequence kernels, never a grid that cannot be resident.  The number is
+// hipDeviceAttributeMultiprocessorCount, which assumes the process has the device to ITSELF: a CU mask (HSA_CU_MASK /
+// ROC_GLOBAL_CU_MASK) or another process's resident kernels are invisible to it, and a grid of exactly that many workgroups
+// would then spin until its bounded waits abort, every step.  NTK_DNC_CU_BUDGET=<n> (read once) overrides the count for such
+// deployments.  A failed query returns 0: every planner then refuses the cluster forms (B * k <= 0 never holds) and the
+// one-workgroup-per-sequence kernels run -- nothing assumes 256.
+#include <stdlib.h>
 int ntk_device_cu_count() {
     static int cache[64];            // 0 = not queried yet (benign race: every writer stores the same value)
+    static int budget = -1;          // -1 = environment not read yet
+    if (__atomic_load_n(&budget, __ATOMIC_RELAXED) < 0) {
+        const char* e = getenv("NTK_DNC_CU_BUDGET");
+        int b = 0;
+        if (e && *e) { b = atoi(e); if (b < 0) b = 0; }
+        __atomic_store_n(&budget, b, __ATOMIC_RELAXED);
+    }
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
-    if (dev >= 0 && dev < 64 && __atomic_load_n(&cache[dev], __ATOMIC_RELAXED) > 0) return cache[dev];
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 256; }
-    if (dev >= 0 && dev < 64) __atomic_store_n(&cache[dev], n, __ATOMIC_RELAXED);
-    return n;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int n = (dev >= 0 && dev < 64) ? __atomic_load_n(&cache[dev], __ATOMIC_RELAXED) : 0;
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
+        if (dev >= 0 && dev < 64) __atomic_store_n(&cache[dev], n, __ATOMIC_RELAXED);
+    }
+    const int b = __atomic_load_n(&budget, __ATOMIC_RELAXED);
+    return (b > 0 && b < n) ? b : n;
 }
 extern "C" int ntk_cu_count(void) { return ntk_device_cu_count(); }

@@ -747,13 +747,19 @@ void dnc_cluster_latch(const unsigned* err, unsigned* sticky, void* stream) {
 }
 
 // device-side propagation of an abort (no host synchronisation): when the sticky word of a workspace is set, the loss
-// becomes NaN and the gradient zero, so the optimiser step that follows is harmless and whoever reads the loss sees it
+// and the WHOLE gradient become NaN.  NaN, not zero: under data parallelism the gradient is SUM all-reduced next, and a
+// rank that contributed zeros would let every other rank step on a partial gradient with no sign of failure; a NaN
+// reaches every rank through the sum, makes the global norm NaN everywhere, and ntk_rmsprop_clip_step_checked then
+// skips the update on all of them.
 __global__ void dnc_cluster_guard_kernel(const unsigned* sticky, float* loss, float* grad, size_t n) {
     if (*sticky == 0u) return;
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
-    if (i0 == 0 && loss) loss[0] = __int_as_float(0x7fc00000);
-    if (grad) for (size_t i = i0; i < n; i += step) grad[i] = 0.f;
+    const float qnan = __int_as_float(0x7fc00000);
+    if (i0 == 0 && loss) loss[0] = qnan;
+    if (grad) for (size_t i = i0; i < n; i += step) grad[i] = qnan;
 }
+
+__global__ void dnc_cluster_inject_kernel(unsigned* sticky) { *sticky = 1u; }
 
 extern "C" int ntk_dnc_cluster_guard(const void* workspace, size_t workspace_bytes, int mp_form, int B, int k, float* loss, float* grad,
                                      size_t n, void* stream) {
@@ -763,6 +769,17 @@ extern "C" int ntk_dnc_cluster_guard(const void* workspace, size_t workspace_byt
     NTK_REQUIRE(!mp_form || workspace_bytes >= 512, NTK_ERR_BAD_PTR, "ntk_dnc_cluster_guard: workspace_bytes");
     dnc_cluster_guard_kernel<<<64, 256, 0, (hipStream_t)stream>>>(stk, loss, grad, grad ? n : 0);
     NTK_CHECK_LAUNCH("ntk_dnc_cluster_guard");
+    return NTK_OK;
+}
+
+// fault injection (tests): sets the sticky error word exactly as a timed-out hand-off does
+extern "C" int ntk_dnc_cluster_inject_abort(void* workspace, size_t workspace_bytes, int mp_form, int B, int k, void* stream) {
+    NTK_REQUIRE(workspace && B > 0 && k > 0, NTK_ERR_BAD_PTR, "ntk_dnc_cluster_inject_abort: bad arguments");
+    NTK_REQUIRE(!mp_form || workspace_bytes >= 512, NTK_ERR_BAD_PTR, "ntk_dnc_cluster_inject_abort: workspace_bytes");
+    char* w = reinterpret_cast<char*>(workspace);
+    unsigned* stk = reinterpret_cast<unsigned*>(mp_form ? w + workspace_bytes - 256 : w + dnc_cluster_ctrl_bytes(B, k) - 256);
+    dnc_cluster_inject_kernel<<<1, 1, 0, (hipStream_t)stream>>>(stk);
+    NTK_CHECK_LAUNCH("ntk_dnc_cluster_inject_abort");
     return NTK_OK;
 }
 

@@ -331,6 +331,33 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
     p[i] -= mo;
 }
 
+// The same update behind a finiteness check of the global norm (every thread reads the same word, so the whole grid takes
+// the same branch): a NaN / Inf norm -- an aborted cluster launch poisons the gradient, csrc/dnc_cluster_fwd.hip, or a
+// genuine overflow -- leaves parameters and slots untouched, turns *loss into NaN and counts the skipped step.
+__global__ void rmsprop_checked_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms,
+                                       float* __restrict__ mom, size_t n, float lr, float decay, float momentum,
+                                       float eps, float clip, const float* __restrict__ gnorm, float* __restrict__ loss,
+                                       unsigned* __restrict__ skipped) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float gn = *gnorm;
+    if (!(fabsf(gn) <= 3.402823466e38f)) {                    // NaN or Inf
+        if (i == 0) {
+            if (loss) loss[0] = __int_as_float(0x7fc00000);
+            if (skipped) *skipped += 1u;
+        }
+        return;
+    }
+    if (i >= n) return;
+    float scale = 1.0f;
+    if (clip > 0.f) scale = clip / fmaxf(gn, clip);
+    const float gi = g[i] * scale;
+    const float m2 = decay * ms[i] + (1.0f - decay) * gi * gi;
+    const float mo = momentum * mom[i] + lr * gi / sqrtf(m2 + eps);
+    ms[i] = m2;
+    mom[i] = mo;
+    p[i] -= mo;
+}
+
 }  // namespace
 
 static int gather_serialize_impl(const float* fmap, const float* gts0, float* X, int B, int T,
@@ -528,5 +555,17 @@ extern "C" int ntk_rmsprop_clip_step(float* params, const float* grads, float* m
     const unsigned nb = (unsigned)((n + 255) / 256);
     rmsprop_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(params, grads, ms, mom, n, lr, decay, momentum, eps, clip_norm, gnorm);
     NTK_CHECK_LAUNCH("ntk_rmsprop_clip_step");
+    return NTK_OK;
+}
+
+extern "C" int ntk_rmsprop_clip_step_checked(float* params, const float* grads, float* ms, float* mom, size_t n,
+                                             float lr, float decay, float momentum, float eps, float clip_norm,
+                                             const float* gnorm, float* loss, unsigned* skipped, void* stream) {
+    NTK_REQUIRE(params && grads && ms && mom && gnorm, NTK_ERR_BAD_PTR, "ntk_rmsprop_clip_step_checked: null pointer");
+    NTK_REQUIRE(n > 0, NTK_ERR_BAD_SHAPE, "ntk_rmsprop_clip_step_checked: n=0");
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    rmsprop_checked_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(params, grads, ms, mom, n, lr, decay, momentum, eps, clip_norm,
+                                                                gnorm, loss, skipped);
+    NTK_CHECK_LAUNCH("ntk_rmsprop_clip_step_checked");
     return NTK_OK;
 }

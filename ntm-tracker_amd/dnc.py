@@ -352,9 +352,10 @@ class DNC(object):
         return self._plan(B, True)
 
     def check_cluster(self, clear=True):
-        """Synchronise and raise if a hand-off of the cluster launches timed out (the last launch; for the memory-partitioned
-        form ANY launch since the last check: its error word is sticky).  Called by the trackers where a training step
-        synchronises anyway, by the tests and at the end of a benchmark."""
+        """Synchronise and raise if a hand-off of the cluster launches timed out (the last launch, or -- sticky word -- any
+        launch since the last check).  `DNCOffsetTracker.check_step()` calls it (the place a training script reads the loss on
+        the host); bench.py calls that after its timed loop.  `clear` applies to the memory-partitioned form only: the
+        LDS-resident form's status call always reads AND clears its sticky word."""
         for c in (self._cluster, self._cluster_b):
             if c is not None and c[1] is not None:
                 form, k, ws, nbytes = c[1]
@@ -365,7 +366,9 @@ class DNC(object):
 
     def guard(self, loss=None, grad=None):
         """Device-side propagation of an aborted cluster launch (no synchronisation): if a hand-off of any cluster launch
-        since the last check_cluster() timed out, `loss` becomes NaN and `grad` zero (ntk_dnc_cluster_guard)."""
+        since the last check_cluster() timed out, `loss` and every element of `grad` become NaN (ntk_dnc_cluster_guard).
+        NaN rather than zero so that the data-parallel SUM all-reduce carries the failure to every rank: the optimiser
+        (RMSPropClip.step -> ntk_rmsprop_clip_step_checked) then skips the update everywhere."""
         for c in (self._cluster, self._cluster_b):
             if c is not None and c[1] is not None:
                 form, k, ws, nbytes = c[1]
@@ -374,6 +377,17 @@ class DNC(object):
                                                             _P(grad) if grad is not None else None,
                                                             grad.numel() if grad is not None else 0, _lib.stream()),
                            "ntk_dnc_cluster_guard")
+
+    def inject_abort(self, B, bwd=False):
+        """Fault injection (tests): set the sticky error word of the forward (or BPTT) cluster workspace at batch B exactly
+        as a timed-out hand-off does.  Returns False when no cluster form runs at this shape."""
+        plan = self._cluster_bwd_plan(B) if bwd else self._cluster_plan(B)
+        if not plan:
+            return False
+        form, k, ws, nbytes = plan
+        _lib.check(_lib.lib().ntk_dnc_cluster_inject_abort(_P(ws), nbytes, 1 if form == "mp" else 0, B, k, _lib.stream()),
+                   "ntk_dnc_cluster_inject_abort")
+        return True
 
     def _may_overlap(self, B):
         """May the re-recording forward pass of segment s - 1 run on a side stream WHILE segment s is back-propagated?

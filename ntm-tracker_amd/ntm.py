@@ -612,13 +612,17 @@ class StackedNTMCell(NTMCell):
         """Python loop over steps (the LoopNTMTracker fallback for deep controllers).  record=True keeps what
         backward_sequence needs."""
         B, S, _ = X.shape
-        logits, outs, steps = [], [], []
+        logits, outs, steps, states = [], [], [], []
         for t in range(S):
             o, l, state, _rec, srec = self._step(X[:, t], state, record)
             outs.append(o); logits.append(l)
             if record:
                 steps.append(srec)
-        return torch.stack(logits, 1), (torch.stack(outs, 1) if want_outputs else None), state, ({"steps": steps} if record else {})
+                states.append(state)
+        # "states": the full state after every step (controller_state = [c_0, h_0, c_1, h_1, ...] as MultiRNNCell packs it),
+        # what the static-unroll trackers hand back (ntm_tracker_new.py:95-100)
+        return torch.stack(logits, 1), (torch.stack(outs, 1) if want_outputs else None), state, \
+            ({"steps": steps, "states": states} if record else {})
 
     def _pad_inputs(self, inputs):
         return inputs
@@ -743,14 +747,26 @@ class PlainNTMTracker(object):
         X = self.cell._pad_inputs(inputs)
         state = state or self.cell.zero_state(B, self.initializer)
         logits, outputs, new, rec = self.cell.run_sequence(X, state, record=True)
-        debugs = {k: rec[k] for k in ("u", "wc", "wv", "w", "M", "read") if k in rec}
-        return outputs, logits, [state] + per_step_states(self.cell, rec, new), debugs
+        return outputs, logits, [state] + per_step_states(self.cell, rec, new), per_step_debugs(rec)
+
+
+def per_step_debugs(rec):
+    """The recorded per-step tensors [B,S,...] of a launch (u, wc, wv, w, M, read: the reference's per-step debug dicts side by
+    side).  A deep controller's step-wise records (StackedNTMCell) are stacked into the same [B,S,...] form."""
+    keys = ("u", "wc", "wv", "w", "M", "read")
+    if "steps" in rec:
+        return {k: torch.cat([st["top"][k] for st in rec["steps"]], dim=1) for k in keys if rec["steps"] and k in rec["steps"][0]["top"]}
+    return {k: rec[k] for k in keys if k in rec}
 
 
 def per_step_states(cell, rec, final):
     """The state after every step of a recorded launch, as the reference's state dicts (ntm_cell.py:223-228): M, w, read and
     controller_state = [c, h] (BasicLSTMCell, state_is_tuple=False; the recorded cell is the step's c, the recorded h its
-    output).  Views / copies of the records only; the last entry is the launch's final state itself."""
+    output).  Views / copies of the records only; the last entry is the launch's final state itself.  A deep controller
+    (StackedNTMCell, controller_num_layers > 1) runs step-wise and records each step's full state, controller_state =
+    [c_0, h_0, c_1, h_1, ...] as MultiRNNCell concatenates it (ntm_cell.py:45-50)."""
+    if "states" in rec:
+        return list(rec["states"][:-1]) + [final]
     hid = cell.dims.hid
     S = rec["M"].shape[1]
     out = []
@@ -791,6 +807,5 @@ class NTMTracker(object):
             X[:, 0, D:D + F] = target                                    # the indicator: target at the first frame, zeros after
         state = self.cell.zero_state(B, self.initializer)
         logits, outputs, new, rec = self.cell.run_sequence(X, state, record=True)
-        debugs = {k: rec[k] for k in ("u", "wc", "wv", "w", "M", "read") if k in rec}
-        return outputs, logits, [state] + per_step_states(self.cell, rec, new), debugs
+        return outputs, logits, [state] + per_step_states(self.cell, rec, new), per_step_debugs(rec)
 

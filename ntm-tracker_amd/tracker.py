@@ -57,16 +57,30 @@ class RMSPropClip(object):
         L = _lib.lib()
         self.ws = torch.empty(max(1, L.ntk_global_norm_workspace_bytes(params.numel) // 4), device=params.flat.device)
         self.gnorm = torch.zeros(1, device=params.flat.device)
+        self.skipped = torch.zeros(1, device=params.flat.device, dtype=torch.int32)     # steps refused on a non-finite norm
         self.global_step = 0
 
-    def step(self):
+    def step(self, loss=None):
+        """One clipped RMSProp update of the flat buffer from `params.grad` (after the data-parallel all-reduce, so the
+        norm -- and the decision below -- is the same on every rank).  A NaN / Inf global norm (a poisoned gradient: an
+        aborted cluster launch on ANY rank, DNC.guard) skips the update on the device: parameters and slots untouched,
+        `loss` (the step's 1-element loss tensor, optional) becomes NaN, `self.skipped` counts it."""
         L, st = _lib.lib(), _lib.stream()
         n = self.p.numel
         _lib.check(L.ntk_global_norm(_P(self.p.grad), n, _P(self.ws), _P(self.gnorm), st), "ntk_global_norm")
-        _lib.check(L.ntk_rmsprop_clip_step(_P(self.p.flat), _P(self.p.grad), _P(self.ms), _P(self.mom), n,
-                                           self.lr, self.decay, self.momentum, self.eps, self.clip, _P(self.gnorm), st),
-                   "ntk_rmsprop_clip_step")
+        _lib.check(L.ntk_rmsprop_clip_step_checked(_P(self.p.flat), _P(self.p.grad), _P(self.ms), _P(self.mom), n,
+                                                   self.lr, self.decay, self.momentum, self.eps, self.clip, _P(self.gnorm),
+                                                   _np(loss), _P(self.skipped), st),
+                   "ntk_rmsprop_clip_step_checked")
         self.global_step += 1
+
+    def check(self):
+        """Synchronises; raises if any step since the last check was skipped on a non-finite gradient norm."""
+        n = int(self.skipped.item())
+        if n:
+            self.skipped.zero_()
+            raise _lib.NtkError("%d optimiser step(s) were skipped: the (all-reduced) gradient norm was not finite -- an aborted "
+                                "cluster launch on some rank, or an overflow" % n)
 
 
 class _Checkpointing(object):
@@ -196,10 +210,30 @@ class _TwoStreamPipeline(object):
         with torch.cuda.stream(s_ntm):
             loss, _pred = self.loss_and_grads(slot["buf"], gts0, offsets)
             parallel.allreduce_gradients(self._flat_grad())
-            self.opt.step()
+            self.opt.step(loss)
             slot["free"] = torch.cuda.Event()
             slot["free"].record(s_ntm)
         return loss
+
+    def check_step(self):
+        """Call where the host reads a step's loss (it synchronises): raises NtkError when a cluster launch of this rank
+        aborted since the last check (DNC.check_cluster: the sticky error word, read and cleared) or when an optimiser step
+        was skipped because the all-reduced gradient was not finite -- which is how an abort on ANOTHER rank shows here.
+        Training scripts exit non-zero on it; nothing was applied for the failed step(s)."""
+        self.join()
+        err = None
+        core = getattr(self, "core", None)
+        if core is not None and hasattr(core, "check_cluster"):
+            try:
+                core.check_cluster()
+            except _lib.NtkError as e:
+                err = e
+        try:
+            self.opt.check()
+        except _lib.NtkError as e:
+            err = err or e
+        if err is not None:
+            raise err
 
     def join(self):
         """Make the caller's stream wait for everything enqueued on the pipeline streams."""
@@ -278,7 +312,7 @@ class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         fmap = self.features(frames)
         loss, _pred = self.loss_and_grads(fmap, gts0, offsets)
         parallel.allreduce_gradients(self.cell.params.grad)
-        self.opt.step()
+        self.opt.step(loss)
         return loss
 
 
@@ -313,15 +347,21 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         # other half: BASELINE configs[2] (256 x 64, B 32) at k = 4 on 128 CUs: 124.1 -> 107.3 ms per step, although the core
         # alone is slower there (89 ms on half the chip vs 69 ms on all of it).
         L, c = _lib.lib(), self.core
+        #: what the constructor chose for TRAINING steps with a trunk to overlap, (form, k) or None = the core's own automatic
+        #: choice (bench.py prints it); infer() on a tracker used for nothing else may set core.cluster_form / cluster_k back
+        #: to None: with no trunk pass beside it the whole-chip LDS-resident form is the faster core (69 vs 89 ms at configs[2])
+        self.cluster_choice = None
         if self.vgg is not None and c.cluster_form is None and c.cluster_k is None and not os.environ.get("NTK_DNC_CLUSTER_FORM") \
                 and not os.environ.get("NTK_DNC_CLUSTER_K"):
-            for k in (2, 4):
+            for k in (4, 2):        # preference order: k = 4 is the measured one (configs[2]); first match wins
                 if 2 * self.B * k <= L.ntk_cu_count() and L.ntk_dnc_mp_compiled_shape(c.N, c.W, c.R, c.Wn, c.hid, c.O, k) > 0:
                     c.cluster_form, c.cluster_k = "mp", k
+                    self.cluster_choice = ("mp", k)
                     # on half a chip the trunk's two half-batch streams only fight each other: one stream
                     # (configs[2]: 111.4 -> 107.3 ms per step; four parts: 113.6)
                     if not os.environ.get("NTK_TRUNK_SPLIT"):
                         self.vgg.split_streams = 1
+                    break
         if os.environ.get("NTK_DNC_SERIAL_TRUNK"):
             self.serial_trunk = os.environ["NTK_DNC_SERIAL_TRUNK"] != "0"
         else:
@@ -357,8 +397,10 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         logits, _state = self.forward_features(fmap, gts0, record=True)
         loss, pred, dlogits = offset_loss(logits, offsets, self.T)
         self.core.backward_sequence(self._X, dlogits, unpack=False)      # the optimiser reads params.grad (packed layout)
-        # a cluster launch that aborted (a hand-off timed out) must not feed the optimiser: loss -> NaN, gradient -> 0, on the
-        # device, without a synchronisation; DNC.check_cluster() raises where the caller next synchronises
+        # a cluster launch that aborted (a hand-off timed out) must not feed the optimiser, on ANY rank: loss -> NaN and
+        # gradient -> NaN on the device, without a synchronisation.  The NaN survives the SUM all-reduce, every rank's global
+        # norm is NaN and RMSPropClip.step skips the update everywhere (and turns every rank's loss into NaN);
+        # check_step() raises where the caller reads the loss
         self.core.guard(loss, self.core.params.grad)
         return loss, pred
 
@@ -368,7 +410,7 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
             raise _lib.NtkError("tracker was built without VGG weights")
         loss, _ = self.loss_and_grads(self.vgg(frames), gts0, offsets)
         parallel.allreduce_gradients(self.core.params.grad)
-        self.opt.step()
+        self.opt.step(loss)
         return loss
 
     def infer(self, frames, gts0):

@@ -34,10 +34,12 @@ def make_tracker(model, B, T, dev):
     return tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=dev, seed=3, learning_rate=1e-2)
 
 
-def run_steps(trk, frames, gts0, offs, steps):
+def run_steps(trk, frames, gts0, offs, steps, before_step=None):
     losses = []
     trk.submit_features(frames)
     for i in range(steps):
+        if before_step is not None:
+            before_step(i)
         losses.append(trk.train_on_submitted(gts0, offs))
         if i + 1 < steps:
             trk.submit_features(frames)
@@ -54,10 +56,28 @@ def main():
     rank, world = parallel.init_from_env(backend=os.environ.get("NTK_DIST_BACKEND", "gloo"))
     lo, hi = parallel.shard_range(GB, rank, world)
     frames, gts0, offs = make_inputs(GB, T)
-    trk = make_tracker(model, hi - lo, T, dev)
+    abort = model == "dnc_abort"          # rank 1's cluster launch "times out" before the LAST step (fault injection)
+    trk = make_tracker("dnc" if abort else model, hi - lo, T, dev)
     parallel.broadcast_parameters(trk._ckpt_params().flat)
-    losses = run_steps(trk, frames[lo * T:hi * T].to(dev), gts0[lo:hi].to(dev), offs[lo:hi].to(dev), steps)
-    torch.save({"flat": trk._ckpt_params().flat.cpu(), "losses": torch.tensor(losses, dtype=torch.float64)}, out)
+    snap = {}
+
+    def before_step(i):
+        if abort and i == steps - 1:
+            torch.cuda.synchronize()
+            snap["flat"] = trk._ckpt_params().flat.cpu()          # parameters after the last good step
+            if rank == 1:
+                assert trk.core.inject_abort(hi - lo), "no cluster form at this shape: nothing to inject"
+    losses = run_steps(trk, frames[lo * T:hi * T].to(dev), gts0[lo:hi].to(dev), offs[lo:hi].to(dev), steps, before_step)
+    res = {"flat": trk._ckpt_params().flat.cpu(), "losses": torch.tensor(losses, dtype=torch.float64)}
+    if abort:
+        from ntmtrack._lib import NtkError
+        try:
+            trk.check_step()
+            raised = 0
+        except NtkError:
+            raised = 1
+        res.update(flat_before_last=snap["flat"], raised=torch.tensor(raised), skipped_after_check=torch.tensor(int(trk.opt.skipped)))
+    torch.save(res, out)
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()

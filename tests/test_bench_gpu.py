@@ -74,3 +74,84 @@ def test_bench_two_ranks_print_one_json_line(cuda, tmp_path):
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert abs(out["value"] - 2 * 2 * 2 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2
     assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
+
+
+def test_bench_gpus_2_without_torchrun_launches_its_own_ranks(cuda):
+    """`python bench.py --gpus 2` the way the driver calls N = 1 (no torch.distributed.run, no WORLD_SIZE): bench.py starts
+    the two ranks itself as a child process, forwards rank 0's ONE JSON line and returns the child's exit code."""
+    import subprocess
+    env = dict(os.environ, NTK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--seq-len", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert "launching 2 ranks as a child process" in res.stderr
+
+
+def test_rccl_world_size_1_training_step_equals_the_undistributed_step(cuda):
+    """RCCL smoke on the one-GPU box: init_process_group("nccl", world_size=1, device_id=...) and one pipelined training
+    step whose SUM all-reduce is issued inside the high-priority core stream -- the first place RCCL
+    initialisation and that stream ordering run at all.  A world of one must change nothing: parameters after the step are
+    bit-equal to the step of a tracker that never saw torch.distributed.  Runs in a child process (a process group is
+    process-global state; the pytest process keeps none)."""
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import torch, torch.distributed as dist
+        import dp_rank_worker as W
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        frames, gts0, offs = W.make_inputs(2, 2)
+        frames, gts0, offs = frames.to(dev), gts0.to(dev), offs.to(dev)
+        res = {}
+        for model in ("ntm", "dnc"):
+            ref = W.make_tracker(model, 2, 2, dev)
+            W.run_steps(ref, frames, gts0, offs, 2)
+            ref.check_step()
+            res[model] = ref._ckpt_params().flat.clone()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from ntmtrack import parallel
+        assert parallel.world() == (0, 1) and dist.get_backend() == "nccl"
+        calls = []
+        real = dist.all_reduce
+        def spy(t, *a, **k):
+            calls.append((torch.cuda.current_stream(dev).priority, t.numel()))
+            return real(t, *a, **k)
+        dist.all_reduce = spy
+        parallel.allreduce_gradients.__globals__["world"] = lambda: (0, 2)     # force the collective at world size 1
+        for model in ("ntm", "dnc"):
+            trk = W.make_tracker(model, 2, 2, dev)
+            n0 = len(calls)
+            W.run_steps(trk, frames, gts0, offs, 2)
+            trk.check_step()
+            assert len(calls) - n0 == 2, calls
+            assert all(p < 0 for p, _ in calls[n0:]), "the all-reduce must be issued inside the high-priority core stream"
+            assert calls[-1][1] == trk._flat_grad().numel()
+            assert torch.equal(trk._ckpt_params().flat, res[model]), model
+        dist.barrier()
+        dist.destroy_process_group()
+        print("RCCL_WORLD1_OK")
+    """) % (ROOT, ROOT, str(_free_port()))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NTK_DIST_BACKEND"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "RCCL_WORLD1_OK" in res.stdout, (res.stdout[-1000:], res.stderr[-3000:])
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p

@@ -354,20 +354,23 @@ def test_dnc_offset_tracker_training_step(cuda):
 
 
 def test_dnc_full_length_bptt_gradients_match_autograd_oracle(cuda):
-    """BASELINE config 3's cell (DNC 256x64, 4 read heads, hidden 200, clip 20) over S = 650 strictly sequential
-    steps (10 serialised frames) of the tracking task, B = 1: loss and every gradient tensor against the float64
+    """BASELINE config 3's cell (DNC 256x64, 4 read heads, hidden 200, clip 20) over its FULL horizon, S = 1300 strictly
+    sequential steps (20 serialised frames) of the tracking task, B = 2: loss and every gradient tensor against the float64
     torch-autograd restatement (direct_offset_output_with_dnc.py:534-541, :615-620).
 
-    With Sonnet's default initialisation the key / strength gradients are 1e-5 .. 1e-6 of the largest gradient and are
-    sums with heavy cancellation: a float32 evaluation of the SAME restatement is itself 0.1 - 0.4 off float64 on
-    those tensors.  The bound per tensor is therefore: within 1e-3 of float64, or no further from float64 than
-    3x what the float32 evaluation of the oracle is.  Both columns are printed."""
+    Two bounds per tensor.  (1) Global scale: max|g_hip - g_f64| <= 1e-5 x the largest gradient entry of ANY tensor --
+    what the clipped RMSProp step sees (clip_by_global_norm works on the whole bucket).  (2) Own scale: within 1e-3 of
+    float64 relative to the tensor's own largest entry, or no further from float64 than 3x what a float32 evaluation of the
+    SAME restatement is -- with Sonnet's default initialisation the key / strength gradients are 1e-5 .. 1e-6 of the
+    largest gradient and are sums with heavy cancellation, so the float32 oracle itself is 0.1 - 0.6 off on them; bound (1)
+    is what keeps those tensors honest (a 180 % error on an entry of 1e-6 passes (2) but not (1) unless it is 1e-6 small).
+    All columns are printed."""
     from oracle import ntm_oracle as O
     from oracle import ntm_oracle_torch as OT
     from oracle import dnc_oracle_torch as DT
     from ntmtrack import dnc as G
     from ntmtrack import tracker
-    B, T = 1, 10
+    B, T = 2, 20
     S = T * 65
     cfg = D.DNCConfig(514, 2, memory_size=256, word_size=64, num_reads=4, num_writes=1, hidden_size=200, clip_value=20)
     rng = np.random.default_rng(23)
@@ -399,13 +402,17 @@ def test_dnc_full_length_bptt_gradients_match_autograd_oracle(cuda):
     torch.cuda.synchronize()
     np.testing.assert_allclose(float(loss.cpu()), loss_ref, rtol=1e-4)
     rel = lambda a_, b_: float(np.max(np.abs(a_ - b_)) / (np.max(np.abs(b_)) + 1e-30))
-    print("full-length (S=650) DNC gradients vs float64 autograd: tensor, max|ref|, HIP error, float32-oracle error")
+    gmax = max(float(np.abs(g64[k]).max()) for k in p)                  # the largest gradient entry of the whole bucket
+    print("full-length (S=%d, B=%d) DNC gradients vs float64 autograd; largest entry of all tensors %.3e" % (S, B, gmax))
+    print("  tensor, max|ref|, HIP error / own scale, float32-oracle error / own scale, HIP error / global scale")
     bad = {}
     for k in sorted(p):
-        e_hip, e_f32 = rel(grads[k].cpu().numpy(), g64[k]), rel(g32[k], g64[k])
-        print("  %-36s %.3e  %.3e  %.3e" % (k, np.abs(g64[k]).max(), e_hip, e_f32))
-        if e_hip > max(1e-3, 3 * e_f32):
-            bad[k] = (e_hip, e_f32)
+        gh = grads[k].cpu().numpy()
+        e_hip, e_f32 = rel(gh, g64[k]), rel(g32[k], g64[k])
+        e_glob = float(np.max(np.abs(gh - g64[k]))) / gmax
+        print("  %-36s %.3e  %.3e  %.3e  %.3e" % (k, np.abs(g64[k]).max(), e_hip, e_f32, e_glob))
+        if e_glob > 1e-5 or e_hip > max(1e-3, 3 * e_f32):
+            bad[k] = (e_hip, e_f32, e_glob)
     assert not bad, bad
 
 
@@ -602,10 +609,12 @@ def test_dnc_segmented_bptt_does_not_overlap_two_cooperative_grids(cuda, form):
 
 def test_dnc_cluster_abort_reaches_the_loss_without_a_sync(cuda):
     """An aborted cluster launch must not feed the optimiser silently: with the workspace's sticky error word set (what a
-    timed-out hand-off does), DNC.guard turns the loss into NaN and the gradient into zeros on the device, and
-    check_cluster raises -- and clears the word."""
+    timed-out hand-off does), DNC.guard turns the loss AND the gradient into NaN on the device (NaN survives the
+    data-parallel SUM all-reduce; zeros would not), the checked optimiser step behind it leaves parameters and slots
+    untouched and counts the skipped step, and check_cluster raises -- and clears the word."""
     from ntmtrack import dnc as G
     from ntmtrack._lib import NtkError
+    from ntmtrack.tracker import RMSPropClip
     for form in ("lds", "mp"):
         core = G.DNC({"memory_size": 64, "word_size": 16, "num_reads": 2, "num_writes": 1}, {"hidden_size": 32}, 2, 20.0,
                      input_dim=20, device=cuda, seed=6)
@@ -617,18 +626,26 @@ def test_dnc_cluster_abort_reaches_the_loss_without_a_sync(cuda):
         core.guard(loss, grad)
         torch.cuda.synchronize()
         assert float(loss) == 1.0 and float(grad.abs().max()) > 0          # clean run: untouched
-        plan = core._cluster_plan(2)
-        ws, nbytes = plan[2], plan[3]
+        opt = RMSPropClip(core.params, 1e-2, 0.9, 0.0, 1e-10, 50.0)
+        before = core.params.flat.clone()
+        opt.step(loss)
+        torch.cuda.synchronize()
+        assert float(loss) == 1.0 and int(opt.skipped) == 0 and not torch.equal(core.params.flat, before)
+        opt.check()
         # plant what mp_wait / the latch kernel write on a timeout: the sticky word of the forward workspace
-        import ctypes
-        from ntmtrack import _lib
-        off = (nbytes - 256) if form == "mp" else None
-        if off is None:                                                     # lds form: last line of the control block
-            off = ((2 * 3 * 4 + 1) * 4 + 255) // 256 * 256
-        ws.view(torch.int32)[off // 4] = 1
+        assert core.inject_abort(2)
+        before, ms0 = core.params.flat.clone(), opt.ms.clone()
         core.guard(loss, grad)
         torch.cuda.synchronize()
-        assert torch.isnan(loss).all() and float(grad.abs().max()) == 0.0
+        assert torch.isnan(loss).all() and torch.isnan(grad).all()
+        loss.fill_(1.0)
+        opt.step(loss)                                                      # NaN norm: nothing applied, loss poisoned, step counted
+        torch.cuda.synchronize()
+        assert torch.equal(core.params.flat, before) and torch.equal(opt.ms, ms0)
+        assert torch.isnan(loss).all() and int(opt.skipped) == 1
+        with pytest.raises(NtkError):
+            opt.check()
+        opt.check()                                                         # the counter was cleared
         with pytest.raises(NtkError):
             core.check_cluster()
         core.check_cluster()                                                # the word was cleared

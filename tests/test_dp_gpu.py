@@ -52,3 +52,30 @@ def test_two_ranks_hip_training_steps_equal_global_batch(cuda, tmp_path, model):
         np.testing.assert_allclose(float(res[0]["losses"][s] + res[1]["losses"][s]), losses[s], rtol=1e-5)
     assert float((res[0]["flat"] - ref).abs().max()) < 1e-6
     assert float((ref - W.make_tracker(model, GB, T, cuda)._ckpt_params().flat.cpu()).abs().max()) > 1e-4      # it trained
+
+
+def test_cluster_abort_on_one_rank_stops_the_step_on_every_rank(cuda, tmp_path):
+    """Data-parallel failure path: rank 1's DNC cluster launch aborts (its sticky error word is planted, as a timed-out
+    hand-off plants it) before the last of three steps.  DNC.guard poisons rank 1's loss and gradient with NaN, the SUM
+    all-reduce carries the NaN to rank 0, and the checked optimiser step applies NOTHING on either rank: parameters equal
+    those after the last good step, bit for bit and on both ranks; both ranks' loss for that step is NaN; check_step()
+    raises on both (rank 1: its error word; rank 0: the skipped step) -- no rank steps on a partial gradient."""
+    GB, T, steps, world = 2, 2, 3, 2
+    port = _free_port()
+    procs, outs = [], []
+    for rank in range(world):
+        out = str(tmp_path / ("rank%d.pt" % rank))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NTK_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_rank_worker.py"), out, str(GB), str(T),
+                                       str(steps), "dnc_abort"], env=env))
+        outs.append(out)
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    res = [torch.load(o, weights_only=True) for o in outs]
+    for r in res:
+        assert torch.isfinite(r["losses"][:steps - 1]).all() and torch.isnan(r["losses"][steps - 1])
+        assert torch.equal(r["flat"], r["flat_before_last"]), "a rank applied an update from a failed step"
+        assert torch.isfinite(r["flat"]).all()
+        assert int(r["raised"]) == 1 and int(r["skipped_after_check"]) == 0
+    assert torch.equal(res[0]["flat"], res[1]["flat"]), "replicas diverged"

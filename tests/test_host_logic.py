@@ -121,3 +121,27 @@ def test_dnc_segment_plan_is_even_and_records_two_tail_segments():
     core.bptt_segment = 50
     assert core._segment_len(4, 195) == 50
     assert DNC.recorded_tail_segments == 2
+
+
+def test_bench_self_launch_starts_n_ranks_as_a_child_and_returns_its_exit_code():
+    """`python bench.py --gpus 2` without WORLD_SIZE (how the driver calls N = 1) must not die of a usage error: it starts
+    `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` as a child process and returns the child's
+    exit code.  No GPU here, so every rank refuses to run (the HIP path has no CPU fallback) and the code is non-zero --
+    what this checks is the mechanism: two ranks were started with RANK / WORLD_SIZE set, and their failure came back."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: tests/test_bench_gpu.py runs the real thing")
+    env = dict(os.environ, NTK_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert "launching 2 ranks as a child process" in res.stderr
+    assert res.stderr.count("no GPU visible") == 2, res.stderr[-2000:]
+    assert not [l for l in res.stdout.splitlines() if l.strip().startswith("{")]

@@ -206,3 +206,38 @@ def test_multilayer_controller_steps_match_oracle(cuda, layers):
     oouts, ologits, _ = O.loop_ntm_tracker(cfg, params, xs)
     np.testing.assert_allclose(logits.cpu().numpy(), ologits, atol=3e-5)
     np.testing.assert_allclose(outs.cpu().numpy(), oouts, atol=3e-5)
+
+
+def test_static_unroll_trackers_on_a_deep_controller_return_every_state(cuda):
+    """PlainNTMTracker / NTMTracker (ntm_tracker_new.py:66-195) on a cell with a 2-layer MultiRNNCell controller (the
+    constructor default is 10 layers, ntm_cell.py:18-20): `states` holds the initial state and the state after every step
+    (S + 1 dicts, :95-100), controller_state = [c_0, h_0, c_1, h_1] as MultiRNNCell packs it -- against the oracle."""
+    from ntmtrack.ntm import PlainNTMTracker, NTMTracker, StackedNTMCell
+    rng = np.random.default_rng(8)
+    kw = dict(mem_size=64, mem_dim=12, shift_range=1, controller_hidden_size=24, controller_num_layers=2,
+              write_head_size=1, read_head_size=2)
+    cfg = O.NTMConfig(11, 3, **kw)
+    params = O.init_params(cfg, rng, scale=0.3)
+    B, S = 2, 6
+    plain = PlainNTMTracker(S, 3, device=cuda, **kw)
+    assert isinstance(plain.cell, StackedNTMCell)
+    plain.cell.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    xs = rng.standard_normal((B, S, 11)).astype(np.float32)
+    outs, logits, states, debugs = plain(torch.from_numpy(xs).to(cuda))
+    oouts, ologits, _fin, ostates = O.loop_ntm_tracker(cfg, params, xs, return_states=True)
+    torch.cuda.synchronize()
+    assert len(states) == S + 1
+    np.testing.assert_allclose(logits.cpu().numpy(), ologits, atol=3e-5)
+    ost0 = O.zero_state(cfg, params, B)
+    for key in ("M", "w", "read", "controller_state"):
+        np.testing.assert_allclose(states[0][key].cpu().numpy(), ost0[key], atol=1e-6, err_msg=key)
+        for t in range(S):
+            assert states[t + 1][key].shape == ostates[t][key].shape, (key, t)
+            np.testing.assert_allclose(states[t + 1][key].cpu().numpy(), ostates[t][key], atol=3e-5, err_msg="%s step %d" % (key, t))
+    assert states[1]["controller_state"].shape == (B, 2 * 24 * 2)
+    assert debugs["w"].shape == (B, S, 3, 64) and debugs["M"].shape == (B, S, 64, 12)
+    # NTMTracker: same cell behind the target-indicator serialisation
+    F = 5
+    trk = NTMTracker(S, B, 3, device=cuda, **kw)
+    _o, l2, st2, _d = trk(torch.from_numpy(xs).to(cuda), torch.rand((B, F), generator=torch.Generator().manual_seed(1)).to(cuda))
+    assert len(st2) == S + 1 and l2.shape == (B, S, 3) and st2[-1]["controller_state"].shape == (B, 2 * 24 * 2)

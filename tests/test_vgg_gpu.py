@@ -373,3 +373,32 @@ def test_vgg_trunk_bf16_fullsize_matches_bf16_oracle(cuda):
     print("bf16 trunk at 224x224 vs bf16 oracle: max %.3e mean %.3e; vs fp64 trunk: %.3e" % (e_max, e_mean, _rel(got, ref32)))
     assert e_max < 2e-2 and e_mean < 1e-3
     assert _rel(got, ref32) < 3e-2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_vgg_trunk_is_frame_invariant_across_chunk_boundaries(cuda, dtype):
+    """BASELINE configs[3] / [4] push 1920 / 3200 frames per step through `VGG16Conv43.__call__`, i.e. through its
+    `F > chunk_frames` loop (two or more chunks, each split over the stream parts).  Here: 160 frames of 224x224 with
+    chunk_frames = 64 -- chunks of 64, 64 and 32 frames, the first two in two stream parts, the last in one -- against
+    ONE-FRAME launches of the same network: bit-identical, frame by frame, for the fp32 F(4x4) trunk and the bf16 trunk
+    (a frame's result may not depend on its position in a chunk, on the chunk's size or on the stream it ran on)."""
+    from ntmtrack import vgg
+    rng = np.random.default_rng(21)
+    ws = O.init_vgg_weights(rng)
+    for k in ws:
+        ws[k] = (ws[k][0], (rng.standard_normal(ws[k][1].shape) * 0.05).astype(np.float32))
+    F = 160
+    base = (rng.uniform(0, 255, size=(8, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)
+    # 160 different frames from 8 random ones: frame f = base[f % 8] rolled by f // 8 pixels (cheap on the host, no two alike)
+    frames = torch.from_numpy(base).to(cuda)
+    frames = torch.stack([torch.roll(frames[f % 8], shifts=f // 8, dims=1) for f in range(F)]).contiguous()
+    net = vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, chunk_frames=64)
+    got = net(frames)
+    torch.cuda.synchronize()
+    assert got.shape == (F, 28, 28, 512) and got.dtype == torch.float32
+    one = vgg.VGG16Conv43(ws, device=cuda, dtype=dtype)
+    for f in range(F):
+        ref = one(frames[f:f + 1])
+        assert torch.equal(got[f:f + 1], ref), "frame %d (chunk %d, position %d) differs from its one-frame launch" % (f, f // 64, f % 64)
+    # and the whole batch in one chunk (what the 640-frame bench pass does)
+    assert torch.equal(vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, chunk_frames=1024)(frames), got)
