@@ -542,15 +542,17 @@ def main():
         cus = int(L_.lib().ntk_cu_count())
         trunk_alone = trunk_alone_probe(trk, frames)
         core_wgs = B * (getattr(trk.core, "last_cluster_k", 1) if args.model == "dnc" else 1)
-        core_ms = ntm_ms if ntm_ms else out["memory_step"]["ms"]
+        # the persistent recurrent kernels alone (the probes above): what the core's workgroups hold their CUs for; the per-stream
+        # event time `ntm_fwd_bwd_opt_stream` also contains the core stream's wait for its features when the trunk is the bound
+        core_ms = out["memory_step"]["ms"] + (out["memory_step_bptt"]["ms"] if args.mode == "train" else 0.0)
         cu_trunk, cu_core = trunk_alone * 1e-3 * cus, core_ms * 1e-3 * min(core_wgs, cus)
         out["breakdown_ms"]["trunk_alone"] = round(trunk_alone, 3)
         out["breakdown_ms"]["cu_seconds"] = {
             "trunk": round(cu_trunk, 3), "core": round(cu_core, 3), "compute_units": cus, "core_workgroups": core_wgs,
             "cu_time_bound_ms": round((cu_trunk + cu_core) / cus * 1e3, 3),
-            "note": "trunk = the trunk pass alone on the idle device x every CU (its grids fill the chip); core = the core pass of the "
-                    "timed region (serialise .. optimiser; the persistent recurrent kernels are all but ~3 ms of it) x the CUs its "
-                    "persistent workgroups hold; cu_time_bound_ms = (trunk + core) / CUs: what the step cannot beat while both streams overlap"}
+            "note": "trunk = the trunk pass alone on the idle device x every CU (its grids fill the chip); core = the recurrent forward + "
+                    "BPTT kernels alone (memory_step.ms + memory_step_bptt.ms) x the CUs their persistent workgroups hold; "
+                    "cu_time_bound_ms = (trunk + core) / CUs: what the step cannot beat while both streams overlap"}
         if not args.no_cpu_baseline and world == 1:
             # the DNC restatement costs ~15 ms per step on the host: a 4-frame sequence keeps the sample inside its time budget
             out["cpu_baseline"] = cpu_baseline(ws, T=20 if args.model == "ntm" else 4, model=args.model,

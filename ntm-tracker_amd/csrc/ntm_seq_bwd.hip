@@ -14,6 +14,8 @@
 // with log(x) -> 0 for x <= 0; l2_normalize differentiates through
 // rsqrt(max(sum x^2, 1e-12)) (zero through the norm when clamped).
 #include "ntm_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 // Diagnostic build only (-DNTK_CL_PROF): s_memtime shares between consecutive workgroup barriers of a step (LDS accumulators)
 #ifdef NTK_CL_PROF
@@ -69,6 +71,7 @@ static void ntm_bwd_lds(const NtmDims& d, int T, int ldkT, int ldhT, NtmBwdLds& 
     int part = ntm_imax(nslP * nout, nslZ * ldkT);
     part = ntm_imax(part, nslH * ldhT);
     part = ntm_imax(part, nslC * d.Md);
+    part = ntm_imax(part, 32 * d.R * d.Md);                  // the wave-specialised form's read columns of B11: 32 row slices
     int o = 0;
     auto take = [&](int n) { int r = o; o += ntm_align4(n); return r; };
     L.part = take(part);
@@ -85,9 +88,29 @@ static void ntm_bwd_lds(const NtmDims& d, int T, int ldkT, int ldhT, NtmBwdLds& 
     L.total = o;
 }
 
-template <int MAXT, bool FIX>
+// WS (benchmark shape only, 768 threads): the h columns of B11 -- d h_{t-1} = dgates_t . Wr^T[:, 80:280], 71 % of the kernel's
+// largest weight stream (42 % of a BPTT step) -- are NOT needed until the LSTM cell backward of the NEXT iteration, ten phases
+// later; only the 80 read columns feed the top of the next iteration.  Waves 10, 11 ("stream", 100 of 128 lanes = one float4
+// column group x one half of the 800 rows) walk those columns in a circle, one lap per step, through a ring of row registers
+// that is never drained, beside the phases of the 640 compute threads, and hand the product over (2 x 200 floats in LDS)
+// before the barrier in front of B10.  Both kinds of wave run the same twelve workgroup barriers per step; the stream waves
+// consume a fixed number of 4-row groups between consecutive barriers (kBwdWsGroups).  Same idea as ntm_seq_fwd_ws.hip.
+constexpr int BWS_RING = 20, BWS_LAP = 400, BWS_NG = BWS_LAP / 4;
+// groups consumed before barriers 1 .. 9 of an iteration (X1, X2, R2, R3, R4, the three parts of B7 / B8, B9), then after
+// barriers 10 and 11 (beside the read columns of B11 and the carry / commit): 100 in all
+constexpr int kBwdWsGroups[11] = {14, 16, 7, 4, 10, 14, 7, 9, 6, 6, 7};
+constexpr int bws_sum(int n) { int s = 0; for (int i = 0; i < n; ++i) s += kBwdWsGroups[i]; return s; }
+static_assert(bws_sum(11) == BWS_NG && BWS_LAP % BWS_RING == 0, "one lap per step; the ring's phase is static");
+template <int N> using bwsic = std::integral_constant<int, N>;
+template <int I0, int I1, class F>
+__device__ __forceinline__ void bws_for(F&& f) {
+    if constexpr (I0 < I1) { f(bwsic<I0>{}); bws_for<I0 + 1, I1>(f); }
+}
+
+template <int MAXT, bool FIX, bool WS = false>
 __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdLds L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(!WS || FIX, "the wave-specialised form exists for the benchmark shape only");
     const int b = blockIdx.x, tid0 = threadIdx.x, T = FIX ? 640 : blockDim.x;
     const int N = FIX ? 128 : a.d.N, Md = FIX ? 20 : a.d.Md, MP = Md | 1, R = FIX ? 4 : a.d.R, Wh = FIX ? 1 : a.d.Wh;
     const int H = R + Wh, hid = FIX ? 200 : a.d.hid, SS = FIX ? 3 : a.d.SS;
@@ -114,6 +137,71 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
     float* sCinv = smem + L.Cinv; float* sCss = smem + L.Css; float* sC2 = smem + L.C2; float* sDkhat = smem + L.Dkhat;
     float* sSw = smem + L.Sw;  float* sRed = smem + L.Red;  float* sDmh = smem + L.Dmh;
     f32x4* sPart4 = reinterpret_cast<f32x4*>(sPart);
+    // WS: d h_{t-1} partials of the stream waves, [2 row halves][200] floats, behind the resident rows of Wa^T
+    float* sPartH = smem + L.total + 32 + NTMB_RES_WA * 600 * 4;
+
+    if constexpr (WS) {
+        if (tid0 >= 640) {
+            // =========================================================== stream waves (see the note above the kernel)
+            const int sidx = min(tid0 - 640, 99);
+            const int cgs = sidx % 50, sls = sidx / 50;              // float4 column group of the h columns, half of the rows
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.WrT + 80), 0,
+                                                                                  (800 * 280 - 80) * (int)sizeof(float), 0x00020000);
+            const unsigned voff = (unsigned)cgs * 16u + (unsigned)sls * (unsigned)(BWS_LAP * 280 * sizeof(float));
+            auto wrow = [&](int r) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, r * (280 * (int)sizeof(float)), 0)); };
+            const float* dgp = sDG + BWS_LAP * sls;                  // this half's dgates (written by B10, read after barrier 10)
+            constexpr int G0 = kBwdWsGroups[9] + kBwdWsGroups[10];   // groups of a lap consumed in the iteration that starts it
+            f32x4 ring[BWS_RING];
+#pragma unroll
+            for (int q = 0; q < BWS_RING; ++q) ring[(4 * G0 + q) % BWS_RING] = wrow((4 * G0 + q) % BWS_LAP);
+            // the first iteration's "product of the step after the last" is the gradient of the final state: dgates are zero
+            // there (the compute waves clear them), so the groups it still runs add nothing to this initial value
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (sls == 0 && a.dcs_fin) acc = *reinterpret_cast<const f32x4*>(a.dcs_fin + (size_t)b * 2 * hid + hid + 4 * cgs);
+            auto group = [&](auto gc) {                              // rows 4 g .. 4 g + 3 of this lane's half
+                constexpr int r = 4 * decltype(gc)::value;
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(dgp + r);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc += hv[q] * ring[(r + q) % BWS_RING];
+                    ring[(r + q) % BWS_RING] = wrow((r + q + BWS_RING) % BWS_LAP);
+                }
+                __builtin_amdgcn_sched_barrier(0);                   // keep the groups in program order (ntm_seq_fwd_ws.hip)
+            };
+            auto finish_lap = [&]() {                                // groups G0 .. 99 with the barriers 1 .. 8 between them, then the hand-over
+                constexpr int c0 = G0, c1 = c0 + kBwdWsGroups[0], c2 = c1 + kBwdWsGroups[1], c3 = c2 + kBwdWsGroups[2],
+                              c4 = c3 + kBwdWsGroups[3], c5 = c4 + kBwdWsGroups[4], c6 = c5 + kBwdWsGroups[5],
+                              c7 = c6 + kBwdWsGroups[6], c8 = c7 + kBwdWsGroups[7];
+                static_assert(c8 + kBwdWsGroups[8] == BWS_NG, "lap");
+                bws_for<c0, c1>(group); __syncthreads();             // 1
+                bws_for<c1, c2>(group); __syncthreads();             // 2
+                bws_for<c2, c3>(group); __syncthreads();             // 3
+                bws_for<c3, c4>(group); __syncthreads();             // 4
+                bws_for<c4, c5>(group); __syncthreads();             // 5
+                bws_for<c5, c6>(group); __syncthreads();             // 6
+                bws_for<c6, c7>(group); __syncthreads();             // 7
+                bws_for<c7, c8>(group); __syncthreads();             // 8
+                bws_for<c8, BWS_NG>(group);
+                // every lane stores (lanes 100 .. 127 shadow lane 99: same address, same value; see ntm_seq_fwd_ws.hip)
+                reinterpret_cast<f32x4*>(sPartH)[sls * 50 + cgs] = acc;
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            };
+            __syncthreads();                                         // initial state, records of the last step committed
+            __syncthreads();                                         // resident rows of Wa^T
+            for (int t = S - 1; t >= 0; --t) {
+                finish_lap();
+                __syncthreads();                                     // 9: the partials of d h_t are in LDS
+                __syncthreads();                                     // 10: dgates_t are in LDS
+                bws_for<0, kBwdWsGroups[9]>(group);
+                __syncthreads();                                     // 11
+                bws_for<kBwdWsGroups[9], G0>(group);
+                __syncthreads();                                     // 12
+            }
+            finish_lap();                                            // d h_{-1}: the gradient of the initial controller state
+            __syncthreads();                                         // (its barriers 1 .. 8 are matched by the compute waves' epilogue)
+            return;
+        }
+    }
 
     // thread roles
     int hh = tid / N, nn = tid - hh * N;                // (head, slot) owner; active iff hh < H
@@ -181,6 +269,9 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         sdZ[i] = v;
     }
     for (int i = tid; i < hid; i += T) sdC[i] = a.dcs_fin ? a.dcs_fin[(size_t)b * 2 * hid + i] : 0.f;
+    if constexpr (WS) {
+        for (int i = tid; i < 4 * hid; i += T) sDG[i] = 0.f;          // the stream waves' first (partial) lap multiplies these
+    }
     prefetch(S - 1);
     commit();
     __syncthreads();
@@ -537,7 +628,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         NTMB_STAMP(8);
         // ------------------------------------------------ B10: LSTM cell backward
         if (tid < hid) {
-            float dh = sdZ[RM + tid];
+            float dh = WS ? sPartH[tid] + sPartH[hid + tid] : sdZ[RM + tid];
             for (int sl = 0; sl < nslH; ++sl) dh += sPart[sl * ldhT + tid];
             const f32x4 g = reinterpret_cast<const f32x4*>(sGt)[tid];
             const float gi = g[0], gj = g[1], gf = g[2], go = g[3];
@@ -555,14 +646,25 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         __syncthreads();
         NTMB_STAMP(9);
         // ------------------------------------------------ B11: d[read_prev; h_prev] = dgates . Wr^T
-        if (tid < nslZ * kg4) {
+        if constexpr (WS) {
+            // the 80 read columns only (20 float4 column groups x 32 row slices of 25): the h columns are the stream waves'
+            const int cg = tid % 20, sl = tid / 20;
+            sPart4[sl * 20 + cg] = ntk_stream_matvec<4>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, sl * 25, sl * 25 + 25, 4 * hid - 1);
+        } else if (tid < nslZ * kg4) {
             const int cg = tid % kg4, sl = tid / kg4;
             const int r0 = sl * nperZ, r1 = min(4 * hid, r0 + nperZ);
             sPart4[sl * kg4 + cg] = ntk_stream_matvec<(MAXT > 768 ? 2 : 8)>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, r0, r1, 4 * hid - 1);
         }
         __syncthreads();
         NTMB_STAMP(10);
-        if (tid < K) {
+        if constexpr (WS) {
+            if (tid < RM) {
+                float s = 0.f;
+#pragma unroll 8
+                for (int sl = 0; sl < 32; ++sl) s += sPart[sl * RM + tid];
+                sdZ[tid] = s;
+            }
+        } else if (tid < K) {
             float s = 0.f;
             for (int sl = 0; sl < nslZ; ++sl) s += sPart[sl * ldkT + tid];
             sdZ[tid] = s;
@@ -579,9 +681,14 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
     for (int i = tid; i < NMd; i += T) a.dM0[(size_t)b * NMd + i] = sdM[(i / Md) * MP + (i % Md)];
     for (int i = tid; i < HN; i += T) a.dw0[(size_t)b * HN + i] = sdW[i];
     for (int i = tid; i < RM; i += T) a.dread0[(size_t)b * RM + i] = sdZ[i];
+    if constexpr (WS) {
+        // the stream waves finish the last lap (d h_{-1}) behind eight more barriers and one for the hand-over
+#pragma unroll
+        for (int i = 0; i < 9; ++i) __syncthreads();
+    }
     for (int i = tid; i < hid; i += T) {
         a.dcs0[(size_t)b * 2 * hid + i] = sdC[i];
-        a.dcs0[(size_t)b * 2 * hid + hid + i] = sdZ[RM + i];
+        a.dcs0[(size_t)b * 2 * hid + hid + i] = WS ? sPartH[i] + sPartH[hid + i] : sdZ[RM + i];
     }
 }
 
@@ -656,14 +763,20 @@ extern "C" int ntk_ntm_seq_bwd(int B, int S, int N, int Md, int R, int Wh, int h
                       T == 640 && !write_first && ldkT == 280 && ldhT == 200);
     size_t lds_bytes = (size_t)L.total * sizeof(float) + 128;                // + the diagnostic build's stamp words
     if (fix) lds_bytes += (size_t)NTMB_RES_WA * (T / (ldhT / 4)) * (ldhT / 4) * sizeof(f32x4);     // resident rows of Wa^T
+    // benchmark shape: the form whose h columns of Wr^T stream beside the step (NTK_NTM_BWD_FORM=res: round 2's kernel, for comparison)
+    const char* form_env = getenv("NTK_NTM_BWD_FORM");
+    const bool ws = fix && !(form_env && form_env[0] == 'r');
+    if (ws) lds_bytes += (size_t)2 * hid * sizeof(float);
     NTK_REQUIRE(lds_bytes <= 160 * 1024, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_bwd: needs %zu B of LDS (> 160 KiB)", lds_bytes);
     {
         static NtkLdsAttrCache lds_cache;
-        const void* const ks[] = {(const void*)ntm_seq_bwd_kernel<768, false>, (const void*)ntm_seq_bwd_kernel<1024, false>, (const void*)ntm_seq_bwd_kernel<768, true>};
-        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 3, "ntk_ntm_seq_bwd");
+        const void* const ks[] = {(const void*)ntm_seq_bwd_kernel<768, false>, (const void*)ntm_seq_bwd_kernel<1024, false>, (const void*)ntm_seq_bwd_kernel<768, true>,
+                                  (const void*)ntm_seq_bwd_kernel<768, true, true>};
+        const int rc_lds = ntk_raise_lds_limit(lds_cache, ks, 4, "ntk_ntm_seq_bwd");
         if (rc_lds != NTK_OK) return rc_lds;
     }
-    if (fix) ntm_seq_bwd_kernel<768, true><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
+    if (ws) ntm_seq_bwd_kernel<768, true, true><<<B, 768, lds_bytes, (hipStream_t)stream>>>(a, L);
+    else if (fix) ntm_seq_bwd_kernel<768, true><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     else if (T <= 768) ntm_seq_bwd_kernel<768, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     else ntm_seq_bwd_kernel<1024, false><<<B, T, lds_bytes, (hipStream_t)stream>>>(a, L);
     NTK_CHECK_LAUNCH("ntk_ntm_seq_bwd");

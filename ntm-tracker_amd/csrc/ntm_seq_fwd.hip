@@ -35,56 +35,8 @@ extern "C" int ntk_ntm_fwd_prof(unsigned long long* out16) {
 #define NTM_STAMP(i) do { } while (0)
 #endif
 
-struct NtmFwdArgs {
-    NtmDims d;
-    // inputs
-    const float* xproj;    // [B,S,4*hid]  X * Wx (columns n' = unit*4+gate), no bias
-    const float* Wr;       // [ldz][4*hid]
-    const float* Wa;       // [ldh][PP]
-    const float* M0;       // [B,N,Md]
-    const float* w0;       // [B,H,N]
-    const float* read0;    // [B,R,Md]
-    const float* cs0;      // [B,2*hid]  (c then h)
-    // outputs
-    float* logits;         // [B,S,O]
-    float* outputs;        // [B,S,O] softmax(logits) or null
-    float* M_out;          // [B,N,Md]
-    float* w_out;          // [B,H,N]
-    float* read_out;       // [B,R,Md]
-    float* cs_out;         // [B,2*hid]
-    // per-step records (all nullable): what LoopNTMTracker writes to its TensorArrays plus the BPTT stash
-    float* st_z;           // [B,S,ldz]   step input [read_prev;h_prev;1;0..]
-    float* st_gates;       // [B,S,4*hid] activated gates (i,j,f,o per unit)
-    float* st_c;           // [B,S,hid]
-    float* st_h;           // [B,S,ldh]   [h';1;0..]
-    float* st_u;           // [B,S,PP]    activated controls, raw shift logits, raw output logits
-    float* st_wc;          // [B,S,H,N]   content-focused weights
-    float* st_wv;          // [B,S,H,N]   shifted weights (before sharpening)
-    float* st_w;           // [B,S,H,N]
-    float* st_M;           // [B,S,N,Md]
-    float* st_read;        // [B,S,R,Md]
-};
-
-static void ntm_fwd_lds(const NtmDims& d, int T, NtmLds& L) {
-    const int MP = d.Md | 1;
-    const int nsl = ntm_imax(1, T / d.hid);
-    const int ncg = d.PP / 4;
-    const int nslB = ntm_imin(ntm_imax(1, T / ncg), d.hid);
-    const int RM = d.R * d.Md;
-    const int nslR = ntm_imin(ntm_imax(1, T / RM), d.N);
-    int o = 0;
-    L.part = o; o += ntm_align4(ntm_imax(ntm_imax(nsl * 4 * d.hid, nslB * d.PP), nslR * RM));
-    L.M = o; o += ntm_align4(d.N * MP);
-    L.W = o; o += ntm_align4(d.H * d.N);
-    L.Wg = o; o += ntm_align4(d.H * d.N);
-    L.Z = o; o += ntm_align4(d.K);
-    L.C = o; o += ntm_align4(d.hid);
-    L.U = o; o += ntm_align4(d.PP);
-    L.Ks = o; o += ntm_align4(d.H * d.Md);
-    L.Cn = o; o += ntm_align4(d.Md);
-    L.Pw = o; o += ntm_align4(d.H * d.N);
-    L.total = o;
-}
+#include "ntm_fwd_args.h"
+#include <stdlib.h>
 
 // FIX = true specialises every dimension to the reference defaults the benchmark configs run
 // (direct_offset_output.py:21-27: mem 128x20, hidden 200, 4 read + 1 write heads, shift_range 1,
@@ -432,6 +384,9 @@ static int ntm_pick_threads(const NtmDims& d) {
     return want;
 }
 
+bool ntm_seq_fwd_ws_takes(const NtmDims& d);                        // ntm_seq_fwd_ws.hip
+int ntm_seq_fwd_ws_launch(const NtmFwdArgs& a, void* stream);
+
 int ntm_validate_dims(const NtmDims& d, const char* who) {
     NTK_REQUIRE(d.B > 0 && d.S > 0, NTK_ERR_BAD_SHAPE, "%s: B=%d S=%d", who, d.B, d.S);
     NTK_REQUIRE(d.N >= 64 && (d.N % 64) == 0 && d.N <= 1024, NTK_ERR_UNSUPPORTED,
@@ -487,6 +442,11 @@ extern "C" int ntk_ntm_seq_fwd(int B, int S, int N, int Md, int R, int Wh, int h
     a.logits = logits; a.outputs = outputs; a.M_out = M_out; a.w_out = w_out; a.read_out = read_out; a.cs_out = cs_out;
     a.st_z = st_z; a.st_gates = st_gates; a.st_c = st_c; a.st_h = st_h; a.st_u = st_u;
     a.st_wc = st_wc; a.st_wv = st_wv; a.st_w = st_w; a.st_M = st_M; a.st_read = st_read;
+    // benchmark shape: the kernel whose recurrent weight stream runs beside the step instead of in front of it (ntm_seq_fwd_ws.hip;
+    // NTK_NTM_FWD_FORM=res selects round 2's resident-rows kernel below, for comparison)
+    const char* form_env = getenv("NTK_NTM_FWD_FORM");               // read per launch (development switch)
+    const bool ws_off = form_env && form_env[0] == 'r';
+    if (!ws_off && ntm_seq_fwd_ws_takes(a.d)) return ntm_seq_fwd_ws_launch(a, stream);
     int T = ntm_pick_threads(a.d);
     NTK_REQUIRE(T >= a.d.N, NTK_ERR_UNSUPPORTED, "ntk_ntm_seq_fwd: mem_size %d exceeds the workgroup", a.d.N);
     NtmLds L;
