@@ -103,6 +103,15 @@ int ntk_vgg_conv3x3_relu_wino43_window_f32(const float* in, const float* u_packe
 int ntk_vgg_conv3x3_relu_wino43_form_f32(const float* in, const float* u_packed, const float* bias, float* out,
                                          int frames, int H, int W, int cin, int cout, int fuse_pool,
                                          int y0, int x0, int y1, int x1, int waves, void* stream);
+/* The eight-wave kernel with CHANNEL-BLOCKED activation maps on either side, [frames][H][C / 8][W][8] (channel blocks of 8
+ * interleaved per image row) -- the layout the layers of a trunk hand to each other: the eight channels of a K step are one
+ * contiguous 32-byte piece per pixel and a patch row is one contiguous run, so the patch staging reads whole cache lines (NHWC:
+ * 32-byte pieces 4 * cin bytes apart).  in_blocked / out_blocked: which side is blocked (0 = NHWC).  Whole frames, any shape the
+ * eight-wave kernel takes.  Same arithmetic and bits as ntk_vgg_conv3x3_relu_wino43_f32.
+ * (vgg.py:155-161: the layers themselves; the layout between them is this library's own business.) */
+int ntk_vgg_conv3x3_relu_wino43_layout_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                           int frames, int H, int W, int cin, int cout, int fuse_pool,
+                                           int in_blocked, int out_blocked, void* stream);
 
 /* slim.max_pool2d [2,2] stride 2 on NHWC fp32 (vgg.py:155-161) as its own launch (ntk_maxpool2x2).
  * The trunk fuses the pool into the epilogue of conv1_2 / conv2_2 / conv3_3 (fuse_pool); this entry point is the

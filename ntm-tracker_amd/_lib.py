@@ -85,6 +85,7 @@ def _sig(lib):
         "ntk_vgg_conv3x3_relu_wino43_f32": (c_int, [P] * 4 + [c_int] * 6 + [P]),
         "ntk_vgg_conv3x3_relu_wino43_window_f32": (c_int, [P] * 4 + [c_int] * 10 + [P]),
         "ntk_vgg_conv3x3_relu_wino43_form_f32": (c_int, [P] * 4 + [c_int] * 11 + [P]),
+        "ntk_vgg_conv3x3_relu_wino43_layout_f32": (c_int, [P] * 4 + [c_int] * 8 + [P]),
         "ntk_maxpool2x2": (c_int, [P, P] + [c_int] * 4 + [P]),
         "ntk_offset_loss_fwd": (c_int, [P] * 4 + [c_int] * 4 + [P]),
         "ntk_offset_loss_bwd": (c_int, [P] * 3 + [c_int] * 4 + [P]),

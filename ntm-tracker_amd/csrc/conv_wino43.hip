@@ -597,7 +597,15 @@ constexpr int W4D = 512;
 __device__ unsigned long long g_w43d_prof[8][12];
 #endif
 
-template <bool POOL, int TW, int TH, int NSUB, int PWS, int SPXS>
+// INB / OUTB: the activation layout on the input / output side.  false = NHWC; true = CHANNEL-BLOCKED per image row,
+// [H][C/8][W][8] per frame: the eight channels of a K step are one contiguous 32-byte piece per pixel and a patch row is one
+// contiguous run, so a wave's staging load covers 1 KB of whole cache lines instead of thirty-two 32-byte pieces 4 * Cin bytes
+// apart (the staging was 9 % of the kernel, ablation bit 5 its upper bound).  Same arithmetic, same bits; only addresses change.
+// The layers of a trunk hand blocked maps to each other (ntk_vgg_conv3x3_relu_wino43_layout_f32); the first reads conv1_1's NHWC
+// map, the last one writes NHWC for gather_serialize.  (Measured on 640 frames, nine layers: NHWC 45.98 ms; whole planes per
+// channel block, [C/8][H][W][8]: 45.27 of 47.27 on a slower box, -4.2 %; blocks interleaved per image row, this form: 43.56, -5.3 %.
+// conv1_1 itself stays NHWC: its store-bound row kernel is 0.45 - 0.7 ms slower writing eight 1 KB runs per wave.)
+template <bool POOL, int TW, int TH, int NSUB, int PWS, int SPXS, bool INB = false, bool OUTB = false>
 __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino43d_kernel(Wino43Args a) {
     constexpr int STILE = TW * TH, NTILE = NSUB * STILE, PW = 4 * TW + 2, PH = 4 * TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
     constexpr int NPXS = NSUB * SPXS;
@@ -687,7 +695,8 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int y = s_sby[q] - 1 + pr, x = s_sbx[q] - 1 + pc;
                 dst[k] = (q * SPXS + pr * PWS + 5 * (pc >> 2) + (pc & 3)) * 2 + c4;
                 if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W)
-                    soff[k] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + c4 * 4) * sizeof(float));
+                    soff[k] = INB ? (unsigned)((((((size_t)(fq - f0) * H + y) * (Cin >> 3)) * W + x) * 8 + c4 * 4) * sizeof(float))
+                                  : (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + c4 * 4) * sizeof(float));
             }
             // ablation bit 5 (timing only, results wrong): the slots of a patch read CONTIGUOUS 16-byte pieces -- what a channel-blocked
             // activation layout [C/8][H][W][8] would give the staging loads (an upper bound: also drops the halo overlap between patches)
@@ -762,8 +771,13 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int tr = ml / TW, tc = ml - tr * TW;
             const int oy = s_sby[mq] + 4 * tr, ox = s_sbx[mq] + 4 * tc;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            // output addressing: NHWC [f][y][x][Cout], or channel-blocked [f][Cout / 8][y][x][8] (n is a multiple of 4)
+            const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+            const size_t xstep = OUTB ? 8 : (size_t)Cout, ystep = (size_t)Cout * Wo;
+            float* const obase = OUTB ? a.out + (size_t)f * Cout * Ho * Wo + (size_t)(n >> 3) * Wo * 8 + (n & 7)
+                                      : a.out + (size_t)f * Cout * Ho * Wo + n;
             if constexpr (POOL) {
-                float* op = a.out + (((size_t)f * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * Cout + n;
+                float* op = obase + (size_t)(oy >> 1) * ystep + (size_t)(ox >> 1) * xstep;
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
@@ -775,10 +789,13 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         v = v + bv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
-                        W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * (W >> 1) + b) * Cout), v);
+                        // blocked output: a lane pair writes 32 bytes of a 128-byte line that the next three stores complete --
+                        // plain stores (L2 merges the line); non-temporal ones would go out as four partial writes
+                        if constexpr (OUTB) *reinterpret_cast<f32x4*>(op + (size_t)aa * ystep + (size_t)b * xstep) = v;
+                        else W43_STORE(reinterpret_cast<f32x4*>(op + (size_t)aa * ystep + (size_t)b * xstep), v);
                     }
             } else {
-                float* op = a.out + (((size_t)f * H + oy) * W + ox) * Cout + n;
+                float* op = obase + (size_t)oy * ystep + (size_t)ox * xstep;
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
@@ -786,7 +803,8 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         f32x4 v = y[aa][b] + bv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], zero[e]);
-                        W43_STORE(reinterpret_cast<f32x4*>(op + ((size_t)aa * W + b) * Cout), v);
+                        if constexpr (OUTB) *reinterpret_cast<f32x4*>(op + (size_t)aa * ystep + (size_t)b * xstep) = v;
+                        else W43_STORE(reinterpret_cast<f32x4*>(op + (size_t)aa * ystep + (size_t)b * xstep), v);
                     }
             }
         }
@@ -808,8 +826,10 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         unsigned soff[NST]; int dst[NST];
         slot_table(soff, dst);
         f32x4 stage[NST];
+        const int kstep_floats = INB ? W * 8 : 8;                    // one K step further: the next channel block of the image row / the next 8 channels of a pixel
         auto stage_load = [&](int cs) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + cs * 8), 0, (int)(in_window - cs * 32), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + (size_t)cs * kstep_floats), 0,
+                                                                                  (int)(in_window - (unsigned)cs * (unsigned)kstep_floats * 4u), 0x00020000);
 #pragma unroll
             for (int k = 0; k < NST; ++k) stage[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, slot_src(soff[k]), 0, W43_STAGE_AUX));
         };
@@ -820,8 +840,8 @@ __global__ __launch_bounds__(W4D) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         {   // prologue: both patches are requested before either is stored: one HBM round trip
             f32x4 stage1[NST];
-            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + (n8 > 1 ? 8 : 0)), 0,
-                                                                                   (int)(in_window - (n8 > 1 ? 32 : 0)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pin + (n8 > 1 ? kstep_floats : 0)), 0,
+                                                                                   (int)(in_window - (n8 > 1 ? (unsigned)kstep_floats * 4u : 0u)), 0x00020000);
             stage_load(0);
 #pragma unroll
             for (int k = 0; k < NST; ++k) stage1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, slot_src(soff[k]), 0, W43_STAGE_AUX));
@@ -1088,7 +1108,8 @@ extern "C" int ntk_vgg_pack_weights_wino43(const float* w_hwio, float* u_packed,
 }
 
 static int wino43_launch(const float* in, const float* u_packed, const float* bias, float* out,
-                         int frames, int H, int W, int cin, int cout, int fuse_pool, int y0, int x0, int y1, int x1, int waves, void* stream) {
+                         int frames, int H, int W, int cin, int cout, int fuse_pool, int y0, int x0, int y1, int x1, int waves, void* stream,
+                         int in_blocked = 0, int out_blocked = 0) {
     NTK_REQUIRE(waves == 4 || waves == 8, NTK_ERR_UNSUPPORTED, "ntk_vgg_conv3x3_relu_wino43: waves=%d (4 or 8 per workgroup)", waves);
     NTK_REQUIRE(in && u_packed && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_wino43_f32: null pointer");
     NTK_REQUIRE(ntk_aligned16(in) && ntk_aligned16(u_packed) && ntk_aligned16(out), NTK_ERR_BAD_PTR,
@@ -1133,9 +1154,18 @@ static int wino43_launch(const float* in, const float* u_packed, const float* bi
     const long long tpf = (long long)a.bxN * a.byN;
     const long long span = ((32 + tpf - 1) / tpf + 1) * (long long)H * W * cin * (long long)sizeof(float);
     const bool dual = waves == 8 && (shape != 3 || span <= 0xfffff0ll);
+    NTK_REQUIRE(!(in_blocked || out_blocked) || dual, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_wino43_layout_f32: channel-blocked maps need the eight-wave kernel "
+                "(in_blocked=%d out_blocked=%d waves=%d, input span of a block %lld B)", in_blocked, out_blocked, waves, span);
 #define W43_LAUNCH(POOL_, TW_, TH_, NSUB_, PWS_, SPXS_)                                                                       \
     do {                                                                                                                      \
-        if (dual) conv3x3_wino43d_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4D, 0, (hipStream_t)stream>>>(a); \
+        if (dual && in_blocked && out_blocked)                                                                                \
+            conv3x3_wino43d_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_, true, true><<<(unsigned)grid, W4D, 0, (hipStream_t)stream>>>(a); \
+        else if (dual && in_blocked)                                                                                          \
+            conv3x3_wino43d_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_, true, false><<<(unsigned)grid, W4D, 0, (hipStream_t)stream>>>(a); \
+        else if (dual && out_blocked)                                                                                         \
+            conv3x3_wino43d_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_, false, true><<<(unsigned)grid, W4D, 0, (hipStream_t)stream>>>(a); \
+        else if (dual) conv3x3_wino43d_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4D, 0, (hipStream_t)stream>>>(a); \
         else conv3x3_wino43_kernel<POOL_, TW_, TH_, NSUB_, PWS_, SPXS_><<<(unsigned)grid, W4T, 0, (hipStream_t)stream>>>(a);  \
     } while (0)
     // PWS / SPXS: pixel-slot strides of a patch row / a sub-block, chosen so that the sixteen lanes of every window
@@ -1171,4 +1201,13 @@ extern "C" int ntk_vgg_conv3x3_relu_wino43_form_f32(const float* in, const float
                                                     int frames, int H, int W, int cin, int cout, int fuse_pool,
                                                     int y0, int x0, int y1, int x1, int waves, void* stream) {
     return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, y0, x0, y1, x1, waves, stream);
+}
+
+// The eight-wave kernel with CHANNEL-BLOCKED activation maps [frames][H][C / 8][W][8] on either side (what the layers of a trunk
+// hand to each other): in_blocked / out_blocked say which side is blocked (0 = NHWC: the first Winograd layer reads conv1_1's NHWC
+// output, the last one writes NHWC for gather_serialize).  Whole frames; same arithmetic and bits as the NHWC entries.
+extern "C" int ntk_vgg_conv3x3_relu_wino43_layout_f32(const float* in, const float* u_packed, const float* bias, float* out,
+                                                      int frames, int H, int W, int cin, int cout, int fuse_pool,
+                                                      int in_blocked, int out_blocked, void* stream) {
+    return wino43_launch(in, u_packed, bias, out, frames, H, W, cin, cout, fuse_pool, 0, 0, H, W, 8, stream, in_blocked, out_blocked);
 }

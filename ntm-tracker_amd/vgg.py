@@ -137,6 +137,68 @@ def conv3x3_relu_wino43(x, u_packed, bias, cin, cout, fuse_pool=False, out=None,
     return out
 
 
+def _wino43_shape(H, W):
+    """Tile-block shape the F(4x4) kernel picks for a frame (csrc/conv_wino43.hip, wino43_launch): 0 = 8x4x1, 1 = 4x4x2, 2 = 2x2x8, 3 = 1x1x32."""
+    gw, gh = W // 4, H // 4
+    for i, (tw, th) in enumerate(((8, 4), (4, 4), (2, 2))):
+        if gw % tw == 0 and gh % th == 0:
+            return i
+    return 3
+
+
+def blocked_trunk_supported(frames, H, W):
+    """Can conv1_2 .. conv4_3 of a [frames,H,W,3] batch hand channel-blocked maps [H][C/8][W][8] to each other?  Every one of them
+    must be a shape of the eight-wave F(4x4) kernel (a 1x1x32-block layer only while its blocks span less than 16 MB of input:
+    there the slot words are packed)."""
+    if H % 32 or W % 32 or H < 32 or W < 32:
+        return False
+    h, w = H, W
+    for _name, cin, cout, pool in VGG_LAYERS[1:]:
+        if not wino43_supported(cin, cout, h, w, frames):
+            return False
+        if _wino43_shape(h, w) == 3:
+            tpf = (w // 4) * (h // 4)
+            if ((32 + tpf - 1) // tpf + 1) * h * w * cin * 4 > 0xfffff0:
+                return False
+        if pool:
+            h //= 2
+            w //= 2
+    return True
+
+
+def conv3x3_relu_wino43_blocked(x, u_packed, bias, cin, cout, fuse_pool=False, out_blocked=True, out=None):
+    """conv3x3_relu_wino43 with channel-blocked maps: the input is blocked [F,H,cin/8,W,8] (5-D) or NHWC [F,H,W,cin] (4-D); the
+    output blocked [F,Ho,cout/8,Wo,8] or NHWC [F,Ho,Wo,cout].  Same arithmetic and bits as the NHWC call (csrc/conv_wino43.hip)."""
+    in_blocked = x.dim() == 5
+    if in_blocked:
+        F, H, CB, W, E = x.shape
+        if CB * 8 != cin or E != 8:
+            raise _lib.NtkError("conv3x3_relu_wino43_blocked: input is %s, layer expects %d channels in blocks of 8" % (tuple(x.shape), cin))
+    else:
+        F, H, W, C = x.shape
+        if C != cin:
+            raise _lib.NtkError("conv3x3_relu_wino43_blocked: input has %d channels, layer expects %d" % (C, cin))
+    oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
+    if out is None:
+        out = torch.empty((F, oh, cout // 8, ow, 8) if out_blocked else (F, oh, ow, cout), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_wino43_layout_f32(_lib.ptr(x), _lib.ptr(u_packed), _lib.ptr(bias), _lib.ptr(out),
+                                                                 F, H, W, cin, cout, 1 if fuse_pool else 0, 1 if in_blocked else 0,
+                                                                 1 if out_blocked else 0,
+                                                                 _lib.stream()), "ntk_vgg_conv3x3_relu_wino43_layout_f32")
+    return out
+
+
+def nhwc_to_blocked(x):
+    """[F,H,W,C] -> [F,H,C/8,W,8] (host-side helper for tests and step-wise callers)."""
+    F, H, W, C = x.shape
+    return x.view(F, H, W, C // 8, 8).permute(0, 1, 3, 2, 4).contiguous()
+
+
+def blocked_to_nhwc(x):
+    F, H, CB, W, E = x.shape
+    return x.permute(0, 1, 3, 2, 4).reshape(F, H, W, CB * E).contiguous()
+
+
 def conv3x3_relu_bf16(x, w_packed, bias, cin, cout, fuse_pool=False, out_f32=False, out=None):
     """bf16 NHWC activations [F,H,W,Cin] -> relu(conv3x3_same(x)+b) in bf16 (or fp32 when out_f32)."""
     F, H, W, C = x.shape
@@ -191,6 +253,12 @@ class VGG16Conv43(object):
         self.algo = algo
         # form of the F(4x4) kernel: None = the library's default (eight waves per workgroup); 4 = round 2's one-wave-per-SIMD kernel
         self.wino_waves = None
+        # activation layout BETWEEN the layers of the F(4x4) fp32 trunk: "blocked" = [H][C/8][W][8] (a K step's eight channels
+        # contiguous per pixel, blocks interleaved per image row: the patch staging reads whole cache lines), "nhwc" = round 3's.
+        # Blocked is the default wherever the eight-wave kernel takes every layer (blocked_trunk_supported); frames, conv1_1's
+        # output and conv4_3's output are NHWC either way; same bits.
+        self.layout = os.environ.get("NTK_TRUNK_LAYOUT", "blocked")
+        self._blocked_ws = {}
         self.packed = {}
         self.packed_wino = {}
         self.packed_wino43 = {}
@@ -228,6 +296,29 @@ class VGG16Conv43(object):
                 raise _lib.NtkError("bf16 trunk runs to conv4_3 only")
             return self._forward_chunk_bf16(frames.contiguous(), out=out)
         x = frames
+        if (self.layout == "blocked" and self.algo == "winograd" and self.wino_waves in (None, 8) and self.features_window is None
+                and upto == "conv4_3" and blocked_trunk_supported(*frames.shape[:3])):
+            # the maps between the layers live in two ping-pong workspaces per (stream, chunk shape), allocated once: a training
+            # loop then makes no allocator calls in its trunk passes (the largest map, conv1_1's, is 12.8 MB per frame)
+            F, H, W, _ = frames.shape
+            key = (torch.cuda.current_stream(frames.device).cuda_stream, F, H, W)
+            ws = self._blocked_ws.get(key)
+            if ws is None:
+                if len(self._blocked_ws) >= 8:                        # shapes come and go (tests, online tracking): keep the table small
+                    self._blocked_ws.clear()
+                ws = (torch.empty(F * H * W * 64, device=frames.device), torch.empty(F * (H // 2) * (W // 2) * 64, device=frames.device))
+                self._blocked_ws[key] = ws
+            wp, b = self.packed["conv1_1"]
+            x = conv3x3_relu(frames, wp, b, 3, 64, out=ws[0][:F * H * W * 64].view(F, H, W, 64))   # NHWC: conv1_2 reads it as it is
+            h, w = H, W
+            for li, (name, cin, cout, pool) in enumerate(VGG_LAYERS[1:]):
+                last = (name == "conv4_3")
+                oh, ow = (h // 2, w // 2) if pool else (h, w)
+                dst = out if last else ws[(li + 1) & 1][:F * oh * ow * cout].view(F, oh, cout // 8, ow, 8)
+                x = conv3x3_relu_wino43_blocked(x, self.packed_wino43[name], self.packed[name][1], cin, cout, fuse_pool=pool,
+                                                out_blocked=not last, out=dst)
+                h, w = oh, ow
+            return x
         for name, cin, cout, pool in VGG_LAYERS:
             wp, b = self.packed[name]
             last = (name == upto)

@@ -402,3 +402,40 @@ def test_vgg_trunk_is_frame_invariant_across_chunk_boundaries(cuda, dtype):
         assert torch.equal(got[f:f + 1], ref), "frame %d (chunk %d, position %d) differs from its one-frame launch" % (f, f // 64, f % 64)
     # and the whole batch in one chunk (what the 640-frame bench pass does)
     assert torch.equal(vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, chunk_frames=1024)(frames), got)
+
+
+def test_blocked_trunk_layers_equal_nhwc_layers_bit_for_bit(cuda):
+    """The channel-blocked activation layout [H][C/8][W][8] between the layers of the F(4x4) trunk changes addresses only: every
+    tile-block shape of the eight-wave kernel (8x4x1, 4x4x2, 2x2x8, 1x1x32; with and without the fused pool; blocked or NHWC on
+    either side) gives exactly the bits of the NHWC call, and the whole 224x224 trunk (which is blocked by default) equals the
+    NHWC trunk bit for bit -- so every parity bound measured on one holds for the other."""
+    from ntmtrack import vgg
+    rng = np.random.default_rng(5)
+    # the F(4x4) kernel, one case per tile-block shape
+    for F, H, W, cin, cout, pool in ((2, 16, 32, 64, 64, True), (3, 16, 16, 64, 128, False), (5, 8, 8, 128, 256, True),
+                                     (3, 28, 28, 256, 512, False), (40, 4, 4, 32, 64, False)):
+        w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        x = torch.from_numpy(np.maximum(rng.standard_normal((F, H, W, cin)), 0).astype(np.float32)).to(cuda)
+        u, bt = vgg.pack_weights_wino43(torch.from_numpy(w).to(cuda)), torch.from_numpy(b).to(cuda)
+        ref = vgg.conv3x3_relu_wino43(x, u, bt, cin, cout, fuse_pool=pool)
+        xb = vgg.nhwc_to_blocked(x)
+        yb = vgg.conv3x3_relu_wino43_blocked(xb, u, bt, cin, cout, fuse_pool=pool, out_blocked=True)
+        yn = vgg.conv3x3_relu_wino43_blocked(xb, u, bt, cin, cout, fuse_pool=pool, out_blocked=False)
+        ynb = vgg.conv3x3_relu_wino43_blocked(x, u, bt, cin, cout, fuse_pool=pool, out_blocked=True)       # NHWC in, blocked out
+        torch.cuda.synchronize()
+        assert yb.shape == (F, ref.shape[1], cout // 8, ref.shape[2], 8)
+        assert torch.equal(yn, ref), (F, H, W, cin, cout, pool)
+        assert torch.equal(vgg.blocked_to_nhwc(yb), ref) and torch.equal(ynb, yb), (F, H, W, cin, cout, pool)
+        assert torch.equal(vgg.nhwc_to_blocked(ref), yb)
+    # whole trunk
+    ws = O.init_vgg_weights(rng)
+    for k in ws:
+        ws[k] = (ws[k][0], (rng.standard_normal(ws[k][1].shape) * 0.05).astype(np.float32))
+    frames = torch.from_numpy(rng.uniform(0, 255, size=(3, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN).to(cuda)
+    net = vgg.VGG16Conv43(ws, device=cuda)
+    assert net.layout == "blocked" and vgg.blocked_trunk_supported(3, 224, 224)
+    yb = net(frames).clone()
+    net.layout = "nhwc"
+    assert torch.equal(net(frames), yb)
+    assert not vgg.blocked_trunk_supported(1, 36, 36)          # falls back to NHWC where a layer is outside the kernel's shapes
