@@ -278,8 +278,12 @@ def test_dnc_bptt_gradients_match_autograd_oracle(cuda, name, Din, O, N, W, R, W
     core.run_sequence(torch.from_numpy(x).to(cuda), gst, record=True)
     assert core.backward_sequence(core.last_X, dout, unpack=False) is None
     again = core._unpack(grad=True)
-    for k in grads:      # (the one-workgroup kernels' reductions are not fixed-order: equal to rounding, not to the bit)
-        assert float((again[k] - grads[k]).abs().max()) <= 1e-5 * float(grads[k].abs().max()) + 1e-12, k
+    # (the one-workgroup kernels' reductions are not fixed-order: equal to rounding, not to the bit.  Rounding of WHAT: a strength /
+    # gate gradient of 1e-6 is a cancelled sum of terms the size of the largest gradients, so its run-to-run difference scales
+    # with those: 1e-5 of the tensor's own scale + 1e-7 of the largest entry of any tensor)
+    gmax_all = max(float(grads[k].abs().max()) for k in grads)
+    for k in grads:
+        assert float((again[k] - grads[k]).abs().max()) <= 1e-5 * float(grads[k].abs().max()) + 1e-7 * gmax_all + 1e-12, k
     assert not bad, bad
 
 
