@@ -69,6 +69,17 @@ int ntk_vgg_pack_weights_bf16(const float* w_hwio, void* w_packed_bf16, int cin,
 int ntk_vgg_conv3x3_relu_bf16(const void* in_bf16, const void* w_packed_bf16, const float* bias, void* out,
                               int frames, int H, int W, int cin, int cout, int fuse_pool, int out_f32,
                               void* stream);
+/* The same operator in PATCH form (csrc/conv_bf16p.hip, round 4): the input of a block of 512 output pixels is staged once per
+ * channel chunk as a patch with its halo and serves all nine taps; weights go through LDS once per workgroup; everything moves by
+ * LDS-DMA.  Takes frames whose sides are multiples of 4 (of 8 with the fused pool), cin a multiple of 32, cout of 64
+ * (ntk_vgg_bf16p_supported says so for a shape; ntk_vgg_conv3x3_relu_bf16 runs the others).  The weights are packed per layer
+ * AND frame shape (ntk_vgg_pack_weights_bf16p: the chunk size depends on H, W): 9 * cin * cout bf16 elements.  Same operand
+ * rounding, accumulation type and output rounding as ntk_vgg_conv3x3_relu_bf16; the summation order differs. */
+size_t ntk_vgg_bf16p_packed_elems(int cin, int cout);
+int ntk_vgg_bf16p_supported(int H, int W, int cin, int cout, int fuse_pool);
+int ntk_vgg_pack_weights_bf16p(const float* w_hwio, void* w_packed_bf16, int cin, int cout, int H, int W, void* stream);
+int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_packed_bf16p, const float* bias, void* out,
+                               int frames, int H, int W, int cin, int cout, int fuse_pool, int out_f32, void* stream);
 int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, const float* bias, void* out_bf16,
                                      int frames, int H, int W, int cin, int cout, void* stream);
 

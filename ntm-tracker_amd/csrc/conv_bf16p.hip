@@ -1,0 +1,513 @@
+// bf16 conv3x3 SAME + bias + ReLU (+ fused 2x2/2 max-pool) for BASELINE config 5's trunk, PATCH form (round 4).
+//
+// conv_bf16.hip's kernel re-stages a 128-pixel x 64-channel A tile from L2 for every one of the nine taps and a 128-column
+// B tile beside it: 512 B of global -> LDS traffic per v_mfma_f32_32x32x16_bf16, at four workgroups per CU exactly the
+// 64 B/clk the fill path has -- the kernel sat at 31 % of the matrix peak with the pipe half idle (three
+// experiments on the tile shape, all bound the same way).  This kernel removes the bytes instead:
+//   * the INPUT of a block of 512 output pixels is staged ONCE per 32-channel chunk as a patch with its one-pixel halo
+//     (sub-blocks of 32x16 / 16x16 / 8x8 / 4x4 pixels, as the Winograd kernels cut a frame) and serves all nine taps: the
+//     operand of tap (dy, dx) is the same LDS image read at a uniform pixel shift;
+//   * the WEIGHTS of a stage (one kernel row = three taps x 32 channels x 128 columns, 24 KB) go through LDS once per
+//     workgroup and are shared by the sixteen 32-pixel tiles;
+//   so a workgroup moves 113 KB of global -> LDS bytes per 1 152 MFMAs of a chunk (98 B per MFMA, a fifth of before), all by
+//   LDS-DMA (buffer_load ... lds: no staging registers, padding pixels are out-of-range lanes that write zeros), double
+//   buffered, one workgroup barrier per stage of 48 MFMAs per wave;
+//   * 8 waves = 4 (pixel tiles) x 2 (column halves), two per SIMD, each 128 pixels x 64 columns (8 accumulator tiles): per
+//     MFMA 768 B of fragment reads, 96 B/clk per CU against the LDS array's 256; both fragment images are XOR-swizzled at
+//     16-byte granularity on the SOURCE side of the DMA (the LDS side of a DMA is lane-linear), ds_read_b128 conflict-free on
+//     runs of sixteen pixels;
+//   * the product is computed TRANSPOSED, D[channel][pixel] (weights as the A operand): a lane then holds four adjacent
+//     channels of one pixel per register quad and stores 8 bytes (bf16) / 16 bytes (fp32) at a time; vertically adjacent
+//     rows of a sub-block live in consecutive tiles of one wave, so the 2x2 pool is a register max + one DPP exchange.
+// Same operator, operand rounding and accumulation type as conv_bf16.hip (bf16 operands, fp32 accumulate, one bf16 rounding
+// on store; vgg.py:155-161); the summation ORDER over (chunk, tap, channel) differs, so results agree to fp32 rounding.
+#include "common.h"
+#include <type_traits>
+
+// Ablation switches (timing only, results wrong; never defined in the product build): bit 0 no DMA after the prologue, bit 1 no
+// workgroup barrier / DMA wait in the K loop, bit 2 fragments not re-read (one set for the whole kernel), bit 3 no MFMAs
+#ifndef BF16P_ABL
+#define BF16P_ABL 0
+#endif
+
+namespace {
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void bp_for(F&& f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); bp_for<I0 + 1, I1>(f); }
+}
+
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PT = 512;                       // threads per workgroup (8 waves)
+constexpr int PNT = 16;                       // 32-pixel tiles per workgroup
+
+struct Bf16pArgs {
+    const __bf16* in; const __bf16* wq; const float* bias; void* out;
+    int frames, H, W, Cin, Cout;
+    int bxN, byN;       // sub-blocks per frame
+    int NQ, NS;         // sub-blocks in all, workgroups per column block
+    int nCB;            // Cout / BN
+};
+
+// One LDS-DMA piece (1 KB per wave): buffer_load_dwordx4 ... lds through inline assembly.  The builtin
+// (__builtin_amdgcn_raw_ptr_buffer_load_lds) is correct but the compiler guards it: it cannot tell the buffer a DMA fills from
+// the one the fragment reads use (both are runtime halves of one array) and puts s_waitcnt vmcnt(0) in front of later DMAs and
+// LDS reads -- every DMA then waits for the one before it to land.  Here the ordering is the kernel's own: one
+// s_waitcnt vmcnt(0) + workgroup barrier per stage.  M0 = LDS byte address of the piece (saved and restored).
+typedef int pv4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void p_dma16(pv4i rs, unsigned lds_addr, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ pv4i p_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    return pv4i{(int)(unsigned)p, (int)(unsigned)(p >> 32), (int)bytes, 0x00020000};
+}
+
+__device__ __forceinline__ pbf16x8 p_as_bf16x8(const f32x4& v) {
+    union { f32x4 f; pbf16x8 b; } u;
+    u.f = v;
+    return u.b;
+}
+
+// 16-byte piece `piece` of LDS pixel / column `idx` lives in slot piece ^ sw(idx): PIECES = 4 (64-byte rows): bits 2..3 of the
+// index; PIECES = 2 (32-byte rows): bit 3 -- sixteen consecutive indices then cover all 64 banks once per ds_read_b128 group
+template <int PIECES>
+__device__ __forceinline__ int p_sw(int idx) { return PIECES == 4 ? ((idx >> 2) & 3) : ((idx >> 3) & 1); }
+
+// HWIO fp32 [3][3][Cin][Cout] -> bf16, the LDS image of every stage in stage order:
+// [cb][chunk][dy][dx][n (BN)][slot (KC/8)][8], slot = piece ^ sw(n)
+template <int BN, int KC>
+__global__ void bf16p_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wq, int Cin, int Cout) {
+    constexpr int PIECES = KC / 8;
+    const size_t total = (size_t)9 * Cin * Cout;
+    const int NC = Cin / KC;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        size_t r = idx >> 3;
+        const int slot = (int)(r % PIECES); r /= PIECES;
+        const int n = (int)(r % BN); r /= BN;
+        const int tap = (int)(r % 9); r /= 9;
+        const int chunk = (int)(r % NC);
+        const int cb = (int)(r / NC);
+        const int piece = slot ^ p_sw<PIECES>(n);
+        const int c = chunk * KC + piece * 8 + e;
+        wq[idx] = (__bf16)w[((size_t)tap * Cin + c) * Cout + (size_t)cb * BN + n];
+    }
+}
+
+template <int BN, int TW, int TH, int NSUB, int KC, bool POOL, bool OUTF32>
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_relu_bf16p_kernel(Bf16pArgs a) {
+    constexpr int PW = TW + 2, PH = TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
+    constexpr int PIXB = KC * 2, PIECES = KC / 8, PPP = 1024 / PIXB;            // bytes per pixel row, 16-B pieces per row, rows per DMA
+    constexpr int NPA = (NPX + PPP - 1) / PPP;                                  // DMA pieces of the patch
+    constexpr int ABYTES = NPA * 1024;
+    // a stage = the taps whose weights share one LDS buffer and one barrier: a kernel row (3 taps) with 32-channel chunks, the whole
+    // chunk (9 taps) with 16-channel chunks (its weights are half the size, and its steps half as many per tap)
+    constexpr int STAPS = KC == 16 ? 9 : 3, SPC = 9 / STAPS;                    // taps per stage, stages per chunk
+    constexpr int SBYTES = STAPS * BN * PIXB, NPB = SBYTES / 1024;              // one stage of weights
+    constexpr int NPAW = (NPA + 7) / 8;                                         // patch pieces per wave
+    constexpr int TM = BN == 128 ? 4 : 2;                                       // pixel tiles per wave (two column tiles either way)
+    constexpr int TPS = (TW * TH) / 32;                                         // tiles per sub-block (0: two sub-blocks per tile)
+    constexpr int K16 = KC / 16;
+    static_assert(NSUB * TW * TH == 32 * PNT, "512 output pixels per workgroup");
+    constexpr int TRB = POOL ? 0 : 8 * TM * 32 * 144;                           // the un-pooled epilogue's transpose image (below)
+    constexpr int LDSB = (2 * ABYTES + 2 * SBYTES) > TRB ? (2 * ABYTES + 2 * SBYTES) : TRB;
+    static_assert(LDSB + 1024 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char s_mem[LDSB];
+    unsigned char (*s_A)[ABYTES] = reinterpret_cast<unsigned char (*)[ABYTES]>(s_mem);
+    unsigned char (*s_B)[SBYTES] = reinterpret_cast<unsigned char (*)[SBYTES]>(s_mem + 2 * ABYTES);
+    __shared__ int s_sbf[NSUB], s_sby[NSUB], s_sbx[NSUB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x, xcd = id & 7, slotid = id >> 3;
+    int cb, sp;
+    if (a.nCB >= 8) {
+        const int kN = a.nCB >> 3;
+        cb = (slotid % kN) * 8 + xcd;
+        sp = slotid / kN;
+    } else {
+        const int per = 8 / a.nCB;
+        cb = xcd % a.nCB;
+        sp = slotid * per + xcd / a.nCB;
+    }
+    if (sp >= a.NS) return;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    if (tid < NSUB) {
+        const int sq = sp * NSUB + tid;
+        if (sq < a.NQ) {
+            const int bx = sq % a.bxN;
+            const int t1 = sq / a.bxN;
+            s_sbf[tid] = t1 / a.byN; s_sby[tid] = TH * (t1 % a.byN); s_sbx[tid] = TW * bx;
+        } else {
+            s_sbf[tid] = -1; s_sby[tid] = 0; s_sbx[tid] = 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- patch DMA: this wave's pieces pa = wave + 8 i; a lane = one 16-byte slot of one LDS pixel row
+    const int f0 = ((sp * NSUB) / a.bxN) / a.byN;
+    const size_t in_left = (size_t)(a.frames - f0) * H * W * Cin * sizeof(__bf16);
+    const unsigned in_bytes = (unsigned)(in_left < 0x7ffffff0ull ? in_left : 0x7ffffff0ull);
+    const __bf16* pin = a.in + (size_t)f0 * H * W * Cin;
+    unsigned aoff[NPAW];
+#pragma unroll
+    for (int i = 0; i < NPAW; ++i) {
+        const int pa = wave + 8 * i;
+        const int lp = pa * PPP + lane / PIECES, slot = lane % PIECES;
+        aoff[i] = 0x80000000u;                                                  // out of range: the DMA writes zeros
+        if (pa < NPA && lp < NPX) {
+            const int q = lp / SPX, rem = lp - q * SPX;
+            const int py = rem / PW, px = rem - py * PW;
+            const int fq = s_sbf[q];
+            const int y = s_sby[q] - 1 + py, x = s_sbx[q] - 1 + px;
+            if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W)
+                aoff[i] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + (slot ^ p_sw<PIECES>(lp)) * 8) * sizeof(__bf16));
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)s_mem;       // LDS byte address of the block
+    auto dma_patch = [&](int chunk, int buf, int i0, int i1) {                 // pieces i0 .. i1 - 1 of this wave
+        const pv4i rs = p_rsrc(pin + (size_t)chunk * KC, in_bytes - (unsigned)chunk * PIXB);
+#pragma unroll
+        for (int i = 0; i < NPAW; ++i) {
+            if (i >= i0 && i < i1 && wave + 8 * i < NPA)
+                p_dma16(rs, lds0 + buf * ABYTES + (wave + 8 * i) * 1024, (int)aoff[i], 0);
+        }
+    };
+    // one patch piece (index i of this wave's NPAW) of `chunk` into buffer `buf`
+    auto dma_patch1 = [&](int chunk, int buf, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const pv4i rs = p_rsrc(pin + (size_t)chunk * KC, in_bytes - (unsigned)chunk * PIXB);
+        if (wave + 8 * i < NPA) p_dma16(rs, lds0 + buf * ABYTES + (wave + 8 * i) * 1024, (int)aoff[i], 0);
+    };
+    const int NC = Cin / KC, NSTG = SPC * NC;
+    const pv4i wrs = p_rsrc(a.wq + (size_t)cb * NSTG * (SBYTES / 2), (unsigned)NSTG * SBYTES);
+    auto dma_weights1 = [&](int stage, int buf, int i) {                      // weight piece wave + 8 i of `stage`
+        const int pb = wave + 8 * i;
+        if (pb < NPB) p_dma16(wrs, lds0 + 2 * ABYTES + buf * SBYTES + pb * 1024, lane * 16, stage * SBYTES + pb * 1024);
+    };
+    auto dma_weights = [&](int stage, int buf) {
+#pragma unroll
+        for (int i = 0; i < (NPB + 7) / 8; ++i) {
+            const int pb = wave + 8 * i;
+            if (pb < NPB) p_dma16(wrs, lds0 + 2 * ABYTES + buf * SBYTES + pb * 1024, lane * 16, stage * SBYTES + pb * 1024);
+        }
+    };
+
+    // ---- wave roles
+    const int wm = BN == 128 ? (wave >> 1) : wave, wn = BN == 128 ? (wave & 1) : 0;
+    const int mcol = lane & 31, kh = lane >> 5;
+    // patch pixel (tap 0,0 = the output pixel itself, halo offset included) of this lane's column in each of its tiles
+    int pix0[TM];
+    int opix[TM];                                                               // output pixel (element offset / Cout) or -1
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int t = wm * TM + tm;
+        int q, y, x;
+        if constexpr (TPS == 0) {                                               // 4x4 sub-blocks: two per tile
+            q = 2 * t + (mcol >> 4); y = (mcol >> 2) & 3; x = mcol & 3;
+        } else {
+            constexpr int RPT = 32 / TW;                                        // rows of a sub-block per tile
+            const int tl = t % TPS, j = mcol / TW;
+            q = t / TPS;
+            y = 2 * ((tl >> 1) * RPT + j) + (tl & 1);                           // rows y, y + 1 sit in consecutive tiles (the pool's pairs)
+            x = mcol % TW;
+        }
+        pix0[tm] = q * SPX + (y + 1) * PW + (x + 1);
+        const int fq = s_sbf[q];
+        const int Y = s_sby[q] + y, X = s_sbx[q] + x;
+        if constexpr (POOL) opix[tm] = fq < 0 ? -1 : ((fq * (H >> 1) + (Y >> 1)) * (W >> 1) + (X >> 1));
+        else opix[tm] = fq < 0 ? -1 : ((fq * H + Y) * W + X);
+    }
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][nt][r] = 0.f;
+    // weight fragment: row n = wn * 64 + nt * 32 + mcol of tap dx, piece 2 k16 + kh
+    const int bn0 = (wn * 64 + mcol) * PIXB, bsw = p_sw<PIECES>(mcol);
+
+    // ---- prologue: patch of chunk 0 and the first stage of weights
+    dma_patch(0, 0, 0, NPAW);
+    dma_weights(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // one stage = one kernel row of one chunk; the three rows are three copies of the body (the patch pieces a stage's DMAs
+    // take are then compile-time indices into aoff[]: indexed at run time the array went to scratch, and every scratch read
+    // waited for all DMAs in flight)
+    auto stage_body = [&](int chunk, auto part_c) {
+        constexpr int part = decltype(part_c)::value;
+        const int s = SPC * chunk + part;
+        const int abuf = chunk & 1, bbuf = s & 1;
+        // The next stage's weights and a third of the next chunk's patch land while this stage multiplies.  Their DMA
+        // instructions are issued ONE PER STEP, behind the step's MFMAs: an LDS-DMA instruction holds its wave's issue for
+        // 60 - 185 cycles, and all eight waves leave the stage's barrier together -- issued in a block at the top of the stage
+        // they stop both waves of every SIMD at once (ablation: 24 % of the kernel); behind eight queued MFMAs the other wave
+        // of the SIMD has the pipe meanwhile.
+        constexpr int NDW = (NPB + 7) / 8;                                       // weight pieces per wave and stage
+        constexpr int NDP = (NPAW + SPC - 1) / SPC;                              // patch pieces per wave and stage
+        const bool more_w = !(BF16P_ABL & 1) && s + 1 < NSTG, more_p = !(BF16P_ABL & 1) && chunk + 1 < NC;
+        auto dma_slot = [&](auto kc) {                                           // k-th DMA of this stage
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < NDW) { if (more_w) dma_weights1(s + 1, bbuf ^ 1, k); }
+            else if constexpr (k < NDW + NDP && part * NDP + (k - NDW) < NPAW) {
+                if (more_p) dma_patch1(chunk + 1, abuf ^ 1, std::integral_constant<int, part * NDP + (k - NDW)>{});
+            }
+        };
+        const unsigned char* Ab = s_A[abuf];
+        const unsigned char* Bb = s_B[bbuf];
+        // the stage's STAPS * K16 steps (tap, 16-channel half), software-pipelined: the fragments of step i + 1 are requested
+        // before the MFMAs of step i (left to itself the compiler reads every fragment right in front of its first MFMA and
+        // waits for it there: four exposed LDS round trips per eight MFMAs)
+        constexpr int NSTEP = STAPS * K16;
+        f32x4 wf[2][2], xf[2][TM];
+        auto load_frags = [&](auto stc, f32x4 (&wfs)[2], f32x4 (&xfs)[TM]) {
+            constexpr int st = decltype(stc)::value, dxi = st / K16, k16 = st % K16;      // dxi: tap inside the stage
+            constexpr int tap = part * STAPS + dxi;
+            constexpr int shift = (tap / 3 - 1) * PW + (tap % 3 - 1);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                wfs[nt] = *reinterpret_cast<const f32x4*>(Bb + (dxi * BN + nt * 32) * PIXB + bn0 + (((2 * k16 + kh) ^ bsw) << 4));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int p = pix0[tm] + shift;
+                xfs[tm] = *reinterpret_cast<const f32x4*>(Ab + p * PIXB + (((2 * k16 + kh) ^ p_sw<PIECES>(p)) << 4));
+            }
+        };
+        auto step = [&](auto stc) {
+            constexpr int st = decltype(stc)::value;
+            if constexpr (st + 1 < NSTEP && !(BF16P_ABL & 4)) load_frags(std::integral_constant<int, st + 1>{}, wf[(st + 1) & 1], xf[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((BF16P_ABL & 8) != 0) return;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[tm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p_as_bf16x8(wf[(BF16P_ABL & 4) ? 0 : (st & 1)][nt]),
+                                                                          p_as_bf16x8(xf[(BF16P_ABL & 4) ? 0 : (st & 1)][tm]), acc[tm][nt], 0, 0, 0);
+            // this step's share of the stage's DMAs (all of them fit the first steps: NDW + NDP <= 2 NSTEP)
+            constexpr int PER = (NDW + NDP + NSTEP - 1) / NSTEP;
+            dma_slot(std::integral_constant<int, st * PER>{});
+            if constexpr (PER > 1) dma_slot(std::integral_constant<int, st * PER + 1>{});
+            static_assert(PER <= 2, "DMAs per step");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (!(BF16P_ABL & 4) || s == 0) load_frags(std::integral_constant<int, 0>{}, wf[0], xf[0]);
+        bp_for<0, NSTEP>(step);
+        if (!(BF16P_ABL & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    };
+    for (int chunk = 0; chunk < NC; ++chunk) {
+        // opaque copies of the per-lane bases: the 72 fragment addresses of a chunk are the same in every chunk, and hoisted out of
+        // this loop they cost more registers than the kernel has left (they went to scratch, and a scratch reload waits for every
+        // DMA in flight)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(pix0[tm]));
+        stage_body(chunk, std::integral_constant<int, 0>{});
+        if constexpr (SPC > 1) {
+            stage_body(chunk, std::integral_constant<int, 1>{});
+            stage_body(chunk, std::integral_constant<int, 2>{});
+        }
+    }
+
+    // ---- epilogue: register r of acc[tm][nt] = channel nt * 32 + 8 (r >> 2) + 4 kh + (r & 3) of this lane's pixel
+    const int nbase = cb * BN + wn * 64 + 4 * kh;
+    if constexpr (POOL) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + nt * 32 + 8 * g;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+                for (int tm = 0; tm < TM; tm += 2) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float m2 = fmaxf(acc[tm][nt][4 * g + e], acc[tm + 1][nt][4 * g + e]);        // rows y, y + 1
+                        v[e] = fmaxf(fmaxf(m2, ntk_dpp<0xB1>(m2)) + bv[e], 0.f);                          // columns x, x ^ 1
+                    }
+                    if (opix[tm] >= 0 && (mcol & 1) == 0) {
+                        if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)opix[tm] * Cout + n) = v;
+                        else {
+                            pbf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                            *reinterpret_cast<pbf16x4*>(reinterpret_cast<__bf16*>(a.out) + (size_t)opix[tm] * Cout + n) = o;
+                        }
+                    }
+                }
+            }
+    } else {
+        // Un-pooled: a lane's four channels are 8 (16) bytes of a pixel whose neighbours in the wave are Cout * 2 (4) bytes away --
+        // stored as they are, every store instruction touches 32 cache lines for 16 (32) bytes each (first version: the six
+        // un-pooled layers ran 5 - 20 % SLOWER than the tile kernel, the three pooled ones 15 - 20 % faster).  So the wave's
+        // 128 pixels x 64 columns go through ITS OWN slice of the (now idle) staging buffers once and come back row by row:
+        // eight lanes = one pixel's 128 contiguous bytes, 16 bytes per lane per store.  Rows are 128 + 16 bytes apart.
+        constexpr int RB = 144;
+        constexpr int WREG = TM * 32 * RB;                                      // bytes per wave
+        static_assert(8 * WREG <= LDSB, "the transpose image fits");
+        unsigned char* tr = s_mem + wave * WREG;
+        constexpr int NPASS = OUTF32 ? 2 : 1;                                   // fp32 rows: one 32-column half at a time
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (OUTF32 && nt != ps) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + nbase + nt * 32 + 8 * g);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[tm][nt][4 * g + e] + bv[e], 0.f);
+                        unsigned char* row = tr + (tm * 32 + mcol) * RB;
+                        if constexpr (OUTF32) *reinterpret_cast<f32x4*>(row + (8 * g + 4 * kh) * 4) = v;
+                        else {
+                            pbf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                            *reinterpret_cast<pbf16x4*>(row + (nt * 32 + 8 * g + 4 * kh) * 2) = o;
+                        }
+                    }
+                }
+            }
+            // read back: piece pi = lane + 64 j of the wave's TM * 32 rows x 8 pieces; row = pi >> 3 -> tile j >> 2, column 8 (j & 3) + (lane >> 3)
+#pragma unroll
+            for (int j = 0; j < TM * 4; ++j) {
+                const int tmr = j >> 2, mr = 8 * (j & 3) + (lane >> 3), piece = lane & 7;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tr + (tmr * 32 + mr) * RB + piece * 16);
+                const int t = wm * TM + tmr;
+                int q, y, x;
+                if constexpr (TPS == 0) { q = 2 * t + (mr >> 4); y = (mr >> 2) & 3; x = mr & 3; }
+                else {
+                    constexpr int RPT = 32 / TW;
+                    const int tl = t % TPS, jj = mr / TW;
+                    q = t / TPS; y = 2 * ((tl >> 1) * RPT + jj) + (tl & 1); x = mr % TW;
+                }
+                const int fq = s_sbf[q];
+                if (fq >= 0) {
+                    const size_t op = ((size_t)(fq * H + s_sby[q] + y) * W + s_sbx[q] + x) * Cout + cb * BN + wn * 64;
+                    if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + op + ps * 32 + piece * 4) = v;
+                    else *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.out) + op + piece * 8) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BN, int KC>
+int bf16p_launch(const Bf16pArgs& a0, int H, int W, int pool, int out_f32, hipStream_t st) {
+    Bf16pArgs a = a0;
+    // sub-block shape: 0 = 32x16 x1, 1 = 16x16 x2, 2 = 8x8 x8, 3 = 4x4 x32 (KC 16 only: its patches are 2.25x the pixels)
+    const int shape = (W % 32 == 0 && H % 16 == 0) ? 0 : ((W % 16 == 0 && H % 16 == 0) ? 1 : ((W % 8 == 0 && H % 8 == 0) ? 2 : 3));
+    static const int TWs[4] = {32, 16, 8, 4}, THs[4] = {16, 16, 8, 4}, NSUBs[4] = {1, 2, 8, 32};
+    a.bxN = W / TWs[shape];
+    a.byN = H / THs[shape];
+    const long long NQ = (long long)a.frames * a.bxN * a.byN;
+    const long long NS = (NQ + NSUBs[shape] - 1) / NSUBs[shape];
+    a.NQ = (int)NQ; a.NS = (int)NS; a.nCB = a.Cout / BN;
+    long long slots;
+    if (a.nCB >= 8) slots = NS * (a.nCB / 8);
+    else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
+    const unsigned grid = (unsigned)(slots * 8);
+#define BF16P_GO(TW_, TH_, NSUB_)                                                                                         \
+    do {                                                                                                                  \
+        if (pool) {                                                                                                       \
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, true><<<grid, PT, 0, st>>>(a);          \
+            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, false><<<grid, PT, 0, st>>>(a);                 \
+        } else {                                                                                                          \
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, true><<<grid, PT, 0, st>>>(a);         \
+            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, false><<<grid, PT, 0, st>>>(a);                \
+        }                                                                                                                 \
+    } while (0)
+    if constexpr (KC == 32) {
+        if (shape == 0) BF16P_GO(32, 16, 1);
+        else if (shape == 1) BF16P_GO(16, 16, 2);
+        else if (shape == 2) BF16P_GO(8, 8, 8);
+        else return NTK_ERR_UNSUPPORTED;
+    } else {
+        if (shape == 3 && !pool) {
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, 4, 4, 32, KC, false, true><<<grid, PT, 0, st>>>(a);
+            else conv3x3_relu_bf16p_kernel<BN, 4, 4, 32, KC, false, false><<<grid, PT, 0, st>>>(a);
+        } else return NTK_ERR_UNSUPPORTED;
+    }
+#undef BF16P_GO
+    return NTK_OK;
+}
+
+}  // namespace
+
+// Which (BN, KC) form a layer shape takes: columns in blocks of 128 where Cout allows (64 otherwise); 32-channel chunks on the
+// rectangular sub-block shapes, 16-channel chunks on 4x4 sub-blocks (frames whose sides are multiples of 4 but not of 8)
+static int bf16p_form(int H, int W, int cin, int cout, int pool, int* bn, int* kc) {
+    if ((H % 4) || (W % 4) || cin % 32 || cout % 64) return 0;
+    const bool rect = (W % 8 == 0 && H % 8 == 0);
+    if (!rect && pool) return 0;
+    *bn = (cout % 128 == 0) ? 128 : 64;
+    *kc = rect ? 32 : 16;
+    const int nCB = cout / *bn;
+    if (!(nCB <= 8 ? (8 % nCB) == 0 : (nCB % 8) == 0)) return 0;
+    return 1;
+}
+
+extern "C" size_t ntk_vgg_bf16p_packed_elems(int cin, int cout) { return (size_t)9 * cin * cout; }
+
+// weights for ntk_vgg_conv3x3_relu_bf16p: the packing depends on the layer's FRAME shape only through the chunk size (H, W
+// multiples of 8: 32-channel chunks; else 16)
+extern "C" int ntk_vgg_pack_weights_bf16p(const float* w_hwio, void* w_packed_bf16, int cin, int cout, int H, int W, void* stream) {
+    NTK_REQUIRE(w_hwio && w_packed_bf16, NTK_ERR_BAD_PTR, "ntk_vgg_pack_weights_bf16p: null pointer");
+    int bn = 0, kc = 0;
+    NTK_REQUIRE(bf16p_form(H, W, cin, cout, 0, &bn, &kc), NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_pack_weights_bf16p: cin=%d (multiple of 32) cout=%d (multiple of 64) H=%d W=%d (multiples of 4)", cin, cout, H, W);
+    __bf16* wq = reinterpret_cast<__bf16*>(w_packed_bf16);
+    hipStream_t st = (hipStream_t)stream;
+    if (bn == 128 && kc == 32) bf16p_pack_kernel<128, 32><<<1024, 256, 0, st>>>(w_hwio, wq, cin, cout);
+    else if (bn == 64 && kc == 32) bf16p_pack_kernel<64, 32><<<1024, 256, 0, st>>>(w_hwio, wq, cin, cout);
+    else if (bn == 128) bf16p_pack_kernel<128, 16><<<1024, 256, 0, st>>>(w_hwio, wq, cin, cout);
+    else bf16p_pack_kernel<64, 16><<<1024, 256, 0, st>>>(w_hwio, wq, cin, cout);
+    NTK_CHECK_LAUNCH("ntk_vgg_pack_weights_bf16p");
+    return NTK_OK;
+}
+
+// 1 when ntk_vgg_conv3x3_relu_bf16p takes the layer shape (else ntk_vgg_conv3x3_relu_bf16 runs it)
+extern "C" int ntk_vgg_bf16p_supported(int H, int W, int cin, int cout, int fuse_pool) {
+    int bn = 0, kc = 0;
+    return bf16p_form(H, W, cin, cout, fuse_pool, &bn, &kc);
+}
+
+extern "C" int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_packed_bf16p, const float* bias, void* out,
+                                          int frames, int H, int W, int cin, int cout, int fuse_pool, int out_f32, void* stream) {
+    NTK_REQUIRE(in_bf16 && w_packed_bf16p && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_bf16p: null pointer");
+    NTK_REQUIRE(ntk_aligned16(in_bf16) && ntk_aligned16(w_packed_bf16p) && ntk_aligned16(out) && ntk_aligned16(bias), NTK_ERR_BAD_PTR,
+                "ntk_vgg_conv3x3_relu_bf16p: pointers must be 16-byte aligned");
+    int bn = 0, kc = 0;
+    NTK_REQUIRE(frames > 0 && H > 0 && W > 0 && bf16p_form(H, W, cin, cout, fuse_pool, &bn, &kc), NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_bf16p: frames=%d H=%d W=%d cin=%d cout=%d pool=%d (H, W multiples of 4 -- of 8 with the pool; "
+                "cin a multiple of 32, cout of 64)", frames, H, W, cin, cout, fuse_pool);
+    NTK_REQUIRE((unsigned long long)2 * H * W * cin * sizeof(__bf16) <= 0x7ffffff0ull && (long long)frames * H * W < (1ll << 31), NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_bf16p: frame too large for 32-bit offsets");
+    Bf16pArgs a;
+    a.in = reinterpret_cast<const __bf16*>(in_bf16); a.wq = reinterpret_cast<const __bf16*>(w_packed_bf16p); a.bias = bias; a.out = out;
+    a.frames = frames; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
+    a.bxN = a.byN = a.NQ = a.NS = a.nCB = 0;
+    int rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (bn == 128 && kc == 32) rc = bf16p_launch<128, 32>(a, H, W, fuse_pool, out_f32, st);
+    else if (bn == 64 && kc == 32) rc = bf16p_launch<64, 32>(a, H, W, fuse_pool, out_f32, st);
+    else if (bn == 128) rc = bf16p_launch<128, 16>(a, H, W, fuse_pool, out_f32, st);
+    else rc = bf16p_launch<64, 16>(a, H, W, fuse_pool, out_f32, st);
+    NTK_REQUIRE(rc == NTK_OK, rc, "ntk_vgg_conv3x3_relu_bf16p: no instantiation for this shape");
+    NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_bf16p");
+    return NTK_OK;
+}

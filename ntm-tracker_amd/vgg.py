@@ -213,6 +213,28 @@ def conv3x3_relu_bf16(x, w_packed, bias, cin, cout, fuse_pool=False, out_f32=Fal
     return out
 
 
+def conv3x3_relu_bf16p(x, w_packed, bias, cin, cout, fuse_pool=False, out_f32=False, out=None):
+    """conv3x3_relu_bf16 in patch form (csrc/conv_bf16p.hip); w_packed from pack_weights_bf16p for THIS frame shape."""
+    F, H, W, C = x.shape
+    if C != cin or x.dtype != torch.bfloat16:
+        raise _lib.NtkError("conv3x3_relu_bf16p: expected bf16 input with %d channels" % cin)
+    oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
+    if out is None:
+        out = torch.empty((F, oh, ow, cout), device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_bf16p(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out), F, H, W,
+                                                     cin, cout, 1 if fuse_pool else 0, 1 if out_f32 else 0, _lib.stream()),
+               "ntk_vgg_conv3x3_relu_bf16p")
+    return out
+
+
+def pack_weights_bf16p(w_hwio, H, W):
+    kh, kw, cin, cout = w_hwio.shape
+    wp = torch.empty(_lib.lib().ntk_vgg_bf16p_packed_elems(cin, cout), device=w_hwio.device, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().ntk_vgg_pack_weights_bf16p(_lib.ptr(w_hwio.contiguous()), _lib.ptr(wp), cin, cout, H, W, _lib.stream()),
+               "ntk_vgg_pack_weights_bf16p")
+    return wp
+
+
 def pack_weights_bf16(w_hwio):
     kh, kw, cin, cout = w_hwio.shape
     wp = torch.empty((cout, 9 * cin), device=w_hwio.device, dtype=torch.bfloat16)
@@ -260,6 +282,10 @@ class VGG16Conv43(object):
         self.layout = os.environ.get("NTK_TRUNK_LAYOUT", "blocked")
         self._blocked_ws = {}
         self.packed = {}
+        self._w_hwio = {}
+        self._packed_bf16p = {}
+        # bf16 trunk: "patch" = csrc/conv_bf16p.hip wherever it takes the layer shape (round 4), "tile" = round 2's kernel
+        self.bf16_form = os.environ.get("NTK_BF16_FORM", "patch")
         self.packed_wino = {}
         self.packed_wino43 = {}
         for name, cin, cout, _pool in VGG_LAYERS:
@@ -270,6 +296,7 @@ class VGG16Conv43(object):
                 raise _lib.NtkError("%s: weight shape %s != (3,3,%d,%d)" % (name, tuple(w.shape), cin, cout))
             if dtype == "bf16" and cin % 64 == 0:
                 self.packed[name] = (pack_weights_bf16(w), b)
+                self._w_hwio[name] = w                     # the patch-form kernel packs per frame shape, on first use
             else:
                 self.packed[name] = (pack_weights(w), b)
                 if dtype == "f32" and algo in ("winograd", "winograd2") and cin % 16 == 0:
@@ -287,7 +314,14 @@ class VGG16Conv43(object):
         for name, cin, cout, pool in VGG_LAYERS[1:]:
             wp, b = self.packed[name]
             last = (name == "conv4_3")
-            x = conv3x3_relu_bf16(x, wp, b, cin, cout, fuse_pool=pool, out_f32=last, out=out if last else None)
+            h, w = x.shape[1], x.shape[2]
+            if self.bf16_form == "patch" and L.ntk_vgg_bf16p_supported(h, w, cin, cout, 1 if pool else 0):
+                key = (name, h % 8 == 0 and w % 8 == 0)
+                if key not in self._packed_bf16p:
+                    self._packed_bf16p[key] = pack_weights_bf16p(self._w_hwio[name], h, w)
+                x = conv3x3_relu_bf16p(x, self._packed_bf16p[key], b, cin, cout, fuse_pool=pool, out_f32=last, out=out if last else None)
+            else:
+                x = conv3x3_relu_bf16(x, wp, b, cin, cout, fuse_pool=pool, out_f32=last, out=out if last else None)
         return x
 
     def forward_chunk(self, frames, upto="conv4_3", out=None):

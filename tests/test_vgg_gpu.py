@@ -99,6 +99,41 @@ def test_conv3x3_relu_bf16_matches_bf16_oracle(cuda, F, H, W, cin, cout, pool, o
         assert np.max(np.abs(got - ref) / (np.abs(ref) + 1e-3 * scale)) < 2.0 ** -8      # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize("F,H,W,cin,cout,pool,out_f32", [
+    (2, 16, 32, 64, 64, True, False),        # 32x16 sub-blocks, 64 columns (conv1_2's form), fused pool
+    (1, 32, 64, 64, 128, False, False),      # 32x16, 128 columns, several blocks per frame
+    (3, 16, 16, 128, 128, True, False),      # 16x16 sub-blocks x 2 (conv2_2's form): a block spans two frames
+    (5, 8, 8, 128, 256, False, False),       # 8x8 sub-blocks x 8: a ragged last block (5 sub-blocks of 8)
+    (2, 24, 8, 256, 256, True, False),       # 8x8 with the pool (conv3_3's form)
+    (3, 28, 28, 256, 512, False, True),      # 4x4 sub-blocks x 32, 16-channel chunks, fp32 output (conv4_3's form), 49 tiles per frame
+    (1, 4, 4, 32, 64, False, False),         # one sub-block
+])
+def test_conv3x3_relu_bf16_patch_form_matches_bf16_oracle(cuda, F, H, W, cin, cout, pool, out_f32):
+    """csrc/conv_bf16p.hip (the patch-resident kernel config 5's trunk runs): every sub-block shape, both column-block widths,
+    the fused pool and the fp32 output, against the bf16-emulating oracle -- same bounds as the tile kernel's test above."""
+    from ntmtrack import vgg, _lib
+    assert _lib.lib().ntk_vgg_bf16p_supported(H, W, cin, cout, 1 if pool else 0) == 1
+    rng = np.random.default_rng(19)
+    x = O.bf16_round(rng.standard_normal((F, H, W, cin)).astype(np.float32))
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    ref = O.conv3x3_same_relu(x.astype(np.float64), O.bf16_round(w).astype(np.float64), b.astype(np.float64))
+    if pool:
+        ref = O.maxpool2x2(ref)
+    wp = vgg.pack_weights_bf16p(torch.from_numpy(w).to(cuda), H, W)
+    out = vgg.conv3x3_relu_bf16p(torch.from_numpy(x).to(cuda).to(torch.bfloat16), wp, torch.from_numpy(b).to(cuda), cin, cout,
+                                 fuse_pool=pool, out_f32=out_f32)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert got.shape == ref.shape
+    scale = np.max(np.abs(ref))
+    if out_f32:
+        assert np.max(np.abs(got - ref)) / scale < 1e-5
+    else:
+        assert np.max(np.abs(got - ref) / (np.abs(ref) + 1e-3 * scale)) < 2.0 ** -8      # one bf16 rounding of the output
+    assert _lib.lib().ntk_vgg_bf16p_supported(12, 12, cin, cout, 1) == 0                # 4x4 sub-blocks have no pooled form: tile kernel
+
+
 def test_vgg_trunk_bf16_matches_bf16_oracle(cuda):
     from ntmtrack import vgg
     rng = np.random.default_rng(43)
