@@ -40,8 +40,6 @@ __device__ __forceinline__ void bp_for(F&& f) {
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PT = 512;                       // threads per workgroup (8 waves)
-constexpr int PNT = 16;                       // 32-pixel tiles per workgroup
 
 struct Bf16pArgs {
     const __bf16* in; const __bf16* wq; const float* bias; void* out;
@@ -99,8 +97,13 @@ __global__ void bf16p_pack_kernel(const float* __restrict__ w, __bf16* __restric
     }
 }
 
-template <int BN, int TW, int TH, int NSUB, int KC, bool POOL, bool OUTF32>
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_relu_bf16p_kernel(Bf16pArgs a) {
+// NW: waves per workgroup.  8: 512 output pixels, one workgroup per CU.  4 (64 columns only): 256 pixels and under 80 KB of LDS,
+// TWO workgroups per CU -- for the layers with few stages (64 input channels: six), where a workgroup's prologue (the first patch
+// and weights have to land before the first MFMA) and epilogue are a third of its life and nothing else overlaps them.
+template <int BN, int TW, int TH, int NSUB, int KC, bool POOL, bool OUTF32, int NW = 8>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_relu_bf16p_kernel(Bf16pArgs a) {
+    constexpr int PNT = 2 * NW;                                                 // 32-pixel tiles per workgroup
+    static_assert(NW == 8 || (NW == 4 && BN == 64), "four-wave workgroups take 64 columns");
     constexpr int PW = TW + 2, PH = TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
     constexpr int PIXB = KC * 2, PIECES = KC / 8, PPP = 1024 / PIXB;            // bytes per pixel row, 16-B pieces per row, rows per DMA
     constexpr int NPA = (NPX + PPP - 1) / PPP;                                  // DMA pieces of the patch
@@ -109,14 +112,14 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // chunk (9 taps) with 16-channel chunks (its weights are half the size, and its steps half as many per tap)
     constexpr int STAPS = KC == 16 ? 9 : 3, SPC = 9 / STAPS;                    // taps per stage, stages per chunk
     constexpr int SBYTES = STAPS * BN * PIXB, NPB = SBYTES / 1024;              // one stage of weights
-    constexpr int NPAW = (NPA + 7) / 8;                                         // patch pieces per wave
+    constexpr int NPAW = (NPA + NW - 1) / NW;                                   // patch pieces per wave
     constexpr int TM = BN == 128 ? 4 : 2;                                       // pixel tiles per wave (two column tiles either way)
     constexpr int TPS = (TW * TH) / 32;                                         // tiles per sub-block (0: two sub-blocks per tile)
     constexpr int K16 = KC / 16;
-    static_assert(NSUB * TW * TH == 32 * PNT, "512 output pixels per workgroup");
-    constexpr int TRB = POOL ? 0 : 8 * TM * 32 * 144;                           // the un-pooled epilogue's transpose image (below)
+    static_assert(NSUB * TW * TH == 32 * PNT, "512 (256) output pixels per workgroup");
+    constexpr int TRB = POOL ? 0 : NW * TM * 32 * 144;                           // the un-pooled epilogue's transpose image (below)
     constexpr int LDSB = (2 * ABYTES + 2 * SBYTES) > TRB ? (2 * ABYTES + 2 * SBYTES) : TRB;
-    static_assert(LDSB + 1024 <= 160 * 1024, "LDS");
+    static_assert(LDSB + 1024 <= (NW == 8 ? 160 : 80) * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char s_mem[LDSB];
     unsigned char (*s_A)[ABYTES] = reinterpret_cast<unsigned char (*)[ABYTES]>(s_mem);
     unsigned char (*s_B)[SBYTES] = reinterpret_cast<unsigned char (*)[SBYTES]>(s_mem + 2 * ABYTES);
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     unsigned aoff[NPAW];
 #pragma unroll
     for (int i = 0; i < NPAW; ++i) {
-        const int pa = wave + 8 * i;
+        const int pa = wave + NW * i;
         const int lp = pa * PPP + lane / PIECES, slot = lane % PIECES;
         aoff[i] = 0x80000000u;                                                  // out of range: the DMA writes zeros
         if (pa < NPA && lp < NPX) {
@@ -174,26 +177,26 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const pv4i rs = p_rsrc(pin + (size_t)chunk * KC, in_bytes - (unsigned)chunk * PIXB);
 #pragma unroll
         for (int i = 0; i < NPAW; ++i) {
-            if (i >= i0 && i < i1 && wave + 8 * i < NPA)
-                p_dma16(rs, lds0 + buf * ABYTES + (wave + 8 * i) * 1024, (int)aoff[i], 0);
+            if (i >= i0 && i < i1 && wave + NW * i < NPA)
+                p_dma16(rs, lds0 + buf * ABYTES + (wave + NW * i) * 1024, (int)aoff[i], 0);
         }
     };
     // one patch piece (index i of this wave's NPAW) of `chunk` into buffer `buf`
     auto dma_patch1 = [&](int chunk, int buf, auto ic) {
         constexpr int i = decltype(ic)::value;
         const pv4i rs = p_rsrc(pin + (size_t)chunk * KC, in_bytes - (unsigned)chunk * PIXB);
-        if (wave + 8 * i < NPA) p_dma16(rs, lds0 + buf * ABYTES + (wave + 8 * i) * 1024, (int)aoff[i], 0);
+        if (wave + NW * i < NPA) p_dma16(rs, lds0 + buf * ABYTES + (wave + NW * i) * 1024, (int)aoff[i], 0);
     };
     const int NC = Cin / KC, NSTG = SPC * NC;
     const pv4i wrs = p_rsrc(a.wq + (size_t)cb * NSTG * (SBYTES / 2), (unsigned)NSTG * SBYTES);
     auto dma_weights1 = [&](int stage, int buf, int i) {                      // weight piece wave + 8 i of `stage`
-        const int pb = wave + 8 * i;
+        const int pb = wave + NW * i;
         if (pb < NPB) p_dma16(wrs, lds0 + 2 * ABYTES + buf * SBYTES + pb * 1024, lane * 16, stage * SBYTES + pb * 1024);
     };
     auto dma_weights = [&](int stage, int buf) {
 #pragma unroll
-        for (int i = 0; i < (NPB + 7) / 8; ++i) {
-            const int pb = wave + 8 * i;
+        for (int i = 0; i < (NPB + NW - 1) / NW; ++i) {
+            const int pb = wave + NW * i;
             if (pb < NPB) p_dma16(wrs, lds0 + 2 * ABYTES + buf * SBYTES + pb * 1024, lane * 16, stage * SBYTES + pb * 1024);
         }
     };
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // 60 - 185 cycles, and all eight waves leave the stage's barrier together -- issued in a block at the top of the stage
         // they stop both waves of every SIMD at once (ablation: 24 % of the kernel); behind eight queued MFMAs the other wave
         // of the SIMD has the pipe meanwhile.
-        constexpr int NDW = (NPB + 7) / 8;                                       // weight pieces per wave and stage
+        constexpr int NDW = (NPB + NW - 1) / NW;                                 // weight pieces per wave and stage
         constexpr int NDP = (NPAW + SPC - 1) / SPC;                              // patch pieces per wave and stage
         const bool more_w = !(BF16P_ABL & 1) && s + 1 < NSTG, more_p = !(BF16P_ABL & 1) && chunk + 1 < NC;
         auto dma_slot = [&](auto kc) {                                           // k-th DMA of this stage
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // eight lanes = one pixel's 128 contiguous bytes, 16 bytes per lane per store.  Rows are 128 + 16 bytes apart.
         constexpr int RB = 144;
         constexpr int WREG = TM * 32 * RB;                                      // bytes per wave
-        static_assert(8 * WREG <= LDSB, "the transpose image fits");
+        static_assert(NW * WREG <= LDSB, "the transpose image fits");
         unsigned char* tr = s_mem + wave * WREG;
         constexpr int NPASS = OUTF32 ? 2 : 1;                                   // fp32 rows: one 32-column half at a time
 #pragma unroll
@@ -406,40 +409,49 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-template <int BN, int KC>
+template <int BN, int KC, int NW>
 int bf16p_launch(const Bf16pArgs& a0, int H, int W, int pool, int out_f32, hipStream_t st) {
     Bf16pArgs a = a0;
-    // sub-block shape: 0 = 32x16 x1, 1 = 16x16 x2, 2 = 8x8 x8, 3 = 4x4 x32 (KC 16 only: its patches are 2.25x the pixels)
-    const int shape = (W % 32 == 0 && H % 16 == 0) ? 0 : ((W % 16 == 0 && H % 16 == 0) ? 1 : ((W % 8 == 0 && H % 8 == 0) ? 2 : 3));
-    static const int TWs[4] = {32, 16, 8, 4}, THs[4] = {16, 16, 8, 4}, NSUBs[4] = {1, 2, 8, 32};
-    a.bxN = W / TWs[shape];
-    a.byN = H / THs[shape];
+    // sub-block shape, eight waves (512 pixels): 0 = 32x16 x1, 1 = 16x16 x2, 2 = 8x8 x8, 3 = 4x4 x32 (KC 16 only: its patches are 2.25x the
+    // pixels); four waves (256 pixels): 0 = 32x8 x1, 1 = 16x16 x1, 2 = 8x8 x4
+    int shape;
+    if (NW == 8) shape = (W % 32 == 0 && H % 16 == 0) ? 0 : ((W % 16 == 0 && H % 16 == 0) ? 1 : ((W % 8 == 0 && H % 8 == 0) ? 2 : 3));
+    else shape = (W % 32 == 0 && H % 8 == 0) ? 0 : ((W % 16 == 0 && H % 16 == 0) ? 1 : ((W % 8 == 0 && H % 8 == 0) ? 2 : 3));
+    static const int TWs[4] = {32, 16, 8, 4}, THs8[4] = {16, 16, 8, 4}, THs4[4] = {8, 16, 8, 4}, NSUB8[4] = {1, 2, 8, 32}, NSUB4[4] = {1, 1, 4, 16};
+    const int TWv = TWs[shape], THv = NW == 8 ? THs8[shape] : THs4[shape], NSUBv = NW == 8 ? NSUB8[shape] : NSUB4[shape];
+    a.bxN = W / TWv;
+    a.byN = H / THv;
     const long long NQ = (long long)a.frames * a.bxN * a.byN;
-    const long long NS = (NQ + NSUBs[shape] - 1) / NSUBs[shape];
+    const long long NS = (NQ + NSUBv - 1) / NSUBv;
     a.NQ = (int)NQ; a.NS = (int)NS; a.nCB = a.Cout / BN;
     long long slots;
     if (a.nCB >= 8) slots = NS * (a.nCB / 8);
     else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
     const unsigned grid = (unsigned)(slots * 8);
-#define BF16P_GO(TW_, TH_, NSUB_)                                                                                         \
-    do {                                                                                                                  \
-        if (pool) {                                                                                                       \
-            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, true><<<grid, PT, 0, st>>>(a);          \
-            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, false><<<grid, PT, 0, st>>>(a);                 \
-        } else {                                                                                                          \
-            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, true><<<grid, PT, 0, st>>>(a);         \
-            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, false><<<grid, PT, 0, st>>>(a);                \
-        }                                                                                                                 \
+#define BF16P_GO(TW_, TH_, NSUB_)                                                                                             \
+    do {                                                                                                                      \
+        if (pool) {                                                                                                           \
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, true, NW><<<grid, 64 * NW, 0, st>>>(a);     \
+            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, false, NW><<<grid, 64 * NW, 0, st>>>(a);            \
+        } else {                                                                                                              \
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, true, NW><<<grid, 64 * NW, 0, st>>>(a);    \
+            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, false, NW><<<grid, 64 * NW, 0, st>>>(a);           \
+        }                                                                                                                     \
     } while (0)
-    if constexpr (KC == 32) {
+    if constexpr (KC == 32 && NW == 8) {
         if (shape == 0) BF16P_GO(32, 16, 1);
         else if (shape == 1) BF16P_GO(16, 16, 2);
         else if (shape == 2) BF16P_GO(8, 8, 8);
         else return NTK_ERR_UNSUPPORTED;
+    } else if constexpr (KC == 32) {
+        if (shape == 0) BF16P_GO(32, 8, 1);
+        else if (shape == 1) BF16P_GO(16, 16, 1);
+        else if (shape == 2) BF16P_GO(8, 8, 4);
+        else return NTK_ERR_UNSUPPORTED;
     } else {
-        if (shape == 3 && !pool) {
-            if (out_f32) conv3x3_relu_bf16p_kernel<BN, 4, 4, 32, KC, false, true><<<grid, PT, 0, st>>>(a);
-            else conv3x3_relu_bf16p_kernel<BN, 4, 4, 32, KC, false, false><<<grid, PT, 0, st>>>(a);
+        if (shape == 3 && !pool && NW == 8) {
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, 4, 4, 32, KC, false, true><<<grid, 512, 0, st>>>(a);
+            else conv3x3_relu_bf16p_kernel<BN, 4, 4, 32, KC, false, false><<<grid, 512, 0, st>>>(a);
         } else return NTK_ERR_UNSUPPORTED;
     }
 #undef BF16P_GO
@@ -448,13 +460,15 @@ int bf16p_launch(const Bf16pArgs& a0, int H, int W, int pool, int out_f32, hipSt
 
 }  // namespace
 
-// Which (BN, KC) form a layer shape takes: columns in blocks of 128 where Cout allows (64 otherwise); 32-channel chunks on the
-// rectangular sub-block shapes, 16-channel chunks on 4x4 sub-blocks (frames whose sides are multiples of 4 but not of 8)
-static int bf16p_form(int H, int W, int cin, int cout, int pool, int* bn, int* kc) {
+// Which (BN, KC, NW) form a layer shape takes: columns in blocks of 128 where Cout allows (64 otherwise); 32-channel chunks on the
+// rectangular sub-block shapes, 16-channel chunks on 4x4 sub-blocks (frames whose sides are multiples of 4 but not of 8); a layer of
+// 64 -> 64 channels (conv1_2: two chunks) on four-wave workgroups, two per CU
+static int bf16p_form(int H, int W, int cin, int cout, int pool, int* bn, int* kc, int* nw) {
     if ((H % 4) || (W % 4) || cin % 32 || cout % 64) return 0;
     const bool rect = (W % 8 == 0 && H % 8 == 0);
     if (!rect && pool) return 0;
-    *bn = (cout % 128 == 0) ? 128 : 64;
+    *nw = (rect && cin <= 64 && cout == 64) ? 4 : 8;       // (measured: conv2_1, 64 -> 128 columns, LOSES 4 % as two 64-column halves that both stage the patch)
+    *bn = (*nw == 8 && cout % 128 == 0) ? 128 : 64;
     *kc = rect ? 32 : 16;
     const int nCB = cout / *bn;
     if (!(nCB <= 8 ? (8 % nCB) == 0 : (nCB % 8) == 0)) return 0;
@@ -467,8 +481,8 @@ extern "C" size_t ntk_vgg_bf16p_packed_elems(int cin, int cout) { return (size_t
 // multiples of 8: 32-channel chunks; else 16)
 extern "C" int ntk_vgg_pack_weights_bf16p(const float* w_hwio, void* w_packed_bf16, int cin, int cout, int H, int W, void* stream) {
     NTK_REQUIRE(w_hwio && w_packed_bf16, NTK_ERR_BAD_PTR, "ntk_vgg_pack_weights_bf16p: null pointer");
-    int bn = 0, kc = 0;
-    NTK_REQUIRE(bf16p_form(H, W, cin, cout, 0, &bn, &kc), NTK_ERR_UNSUPPORTED,
+    int bn = 0, kc = 0, nw = 0;
+    NTK_REQUIRE(bf16p_form(H, W, cin, cout, 0, &bn, &kc, &nw), NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_pack_weights_bf16p: cin=%d (multiple of 32) cout=%d (multiple of 64) H=%d W=%d (multiples of 4)", cin, cout, H, W);
     __bf16* wq = reinterpret_cast<__bf16*>(w_packed_bf16);
     hipStream_t st = (hipStream_t)stream;
@@ -482,8 +496,8 @@ extern "C" int ntk_vgg_pack_weights_bf16p(const float* w_hwio, void* w_packed_bf
 
 // 1 when ntk_vgg_conv3x3_relu_bf16p takes the layer shape (else ntk_vgg_conv3x3_relu_bf16 runs it)
 extern "C" int ntk_vgg_bf16p_supported(int H, int W, int cin, int cout, int fuse_pool) {
-    int bn = 0, kc = 0;
-    return bf16p_form(H, W, cin, cout, fuse_pool, &bn, &kc);
+    int bn = 0, kc = 0, nw = 0;
+    return bf16p_form(H, W, cin, cout, fuse_pool, &bn, &kc, &nw);
 }
 
 extern "C" int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_packed_bf16p, const float* bias, void* out,
@@ -491,8 +505,8 @@ extern "C" int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_pac
     NTK_REQUIRE(in_bf16 && w_packed_bf16p && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_bf16p: null pointer");
     NTK_REQUIRE(ntk_aligned16(in_bf16) && ntk_aligned16(w_packed_bf16p) && ntk_aligned16(out) && ntk_aligned16(bias), NTK_ERR_BAD_PTR,
                 "ntk_vgg_conv3x3_relu_bf16p: pointers must be 16-byte aligned");
-    int bn = 0, kc = 0;
-    NTK_REQUIRE(frames > 0 && H > 0 && W > 0 && bf16p_form(H, W, cin, cout, fuse_pool, &bn, &kc), NTK_ERR_UNSUPPORTED,
+    int bn = 0, kc = 0, nw = 0;
+    NTK_REQUIRE(frames > 0 && H > 0 && W > 0 && bf16p_form(H, W, cin, cout, fuse_pool, &bn, &kc, &nw), NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_bf16p: frames=%d H=%d W=%d cin=%d cout=%d pool=%d (H, W multiples of 4 -- of 8 with the pool; "
                 "cin a multiple of 32, cout of 64)", frames, H, W, cin, cout, fuse_pool);
     NTK_REQUIRE((unsigned long long)2 * H * W * cin * sizeof(__bf16) <= 0x7ffffff0ull && (long long)frames * H * W < (1ll << 31), NTK_ERR_UNSUPPORTED,
@@ -503,10 +517,11 @@ extern "C" int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_pac
     a.bxN = a.byN = a.NQ = a.NS = a.nCB = 0;
     int rc;
     hipStream_t st = (hipStream_t)stream;
-    if (bn == 128 && kc == 32) rc = bf16p_launch<128, 32>(a, H, W, fuse_pool, out_f32, st);
-    else if (bn == 64 && kc == 32) rc = bf16p_launch<64, 32>(a, H, W, fuse_pool, out_f32, st);
-    else if (bn == 128) rc = bf16p_launch<128, 16>(a, H, W, fuse_pool, out_f32, st);
-    else rc = bf16p_launch<64, 16>(a, H, W, fuse_pool, out_f32, st);
+    if (nw == 4) rc = bf16p_launch<64, 32, 4>(a, H, W, fuse_pool, out_f32, st);
+    else if (bn == 128 && kc == 32) rc = bf16p_launch<128, 32, 8>(a, H, W, fuse_pool, out_f32, st);
+    else if (bn == 64 && kc == 32) rc = bf16p_launch<64, 32, 8>(a, H, W, fuse_pool, out_f32, st);
+    else if (bn == 128) rc = bf16p_launch<128, 16, 8>(a, H, W, fuse_pool, out_f32, st);
+    else rc = bf16p_launch<64, 16, 8>(a, H, W, fuse_pool, out_f32, st);
     NTK_REQUIRE(rc == NTK_OK, rc, "ntk_vgg_conv3x3_relu_bf16p: no instantiation for this shape");
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_bf16p");
     return NTK_OK;

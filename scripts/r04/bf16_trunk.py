@@ -19,10 +19,17 @@ def t_ms(fn, n=5):
     return float(np.median(ts))
 out = torch.empty((F, 28, 28, 512), device=dev)
 flops = vgg.conv_flops_per_frame() * F
-for form in ("tile", "patch"):
+for form, split in (("tile", 1), ("patch", 1), ("patch", 2)):
     net.bf16_form = form
+    net.split_streams = split
     ms = t_ms(lambda: net(frames, out=out))
-    print("%s trunk pass: %.3f ms = %.0f TFLOP/s (%.1f %% of 2.5 PF)" % (form, ms, flops / ms / 1e9, 100 * flops / ms / 1e9 / 2500), flush=True)
+    print("%s trunk pass, %d stream part(s): %.3f ms = %.0f TFLOP/s (%.1f %% of 2.5 PF)" % (form, split, ms, flops / ms / 1e9, 100 * flops / ms / 1e9 / 2500), flush=True)
+net.split_streams = 1
+from ntmtrack import _lib
+wp11, b11 = net.packed["conv1_1"]
+x11 = torch.empty((F, 224, 224, 64), device=dev, dtype=torch.bfloat16)
+t11 = t_ms(lambda: _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_f32_to_bf16(_lib.ptr(frames), _lib.ptr(wp11), _lib.ptr(b11), _lib.ptr(x11), F, 224, 224, 3, 64, _lib.stream()), "c11"))
+print("conv1_1 (fp32 frames -> bf16): %.3f ms = %.2f TB/s of stores" % (t11, F * 224 * 224 * 64 * 2 / t11 / 1e9), flush=True)
 x = torch.relu(torch.randn((F, 224, 224, 64), device=dev)).to(torch.bfloat16)
 h = w = 224
 tot_t = tot_p = 0.0
