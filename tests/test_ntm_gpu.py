@@ -241,3 +241,35 @@ def test_static_unroll_trackers_on_a_deep_controller_return_every_state(cuda):
     trk = NTMTracker(S, B, 3, device=cuda, **kw)
     _o, l2, st2, _d = trk(torch.from_numpy(xs).to(cuda), torch.rand((B, F), generator=torch.Generator().manual_seed(1)).to(cuda))
     assert len(st2) == S + 1 and l2.shape == (B, S, 3) and st2[-1]["controller_state"].shape == (B, 2 * 24 * 2)
+
+
+@pytest.mark.parametrize("S", [1, 2, 7])
+def test_wave_specialised_kernels_equal_the_resident_form_on_short_sequences(cuda, monkeypatch, S):
+    """The benchmark shape runs the wave-specialised sequence kernels (csrc/ntm_seq_fwd_ws.hip, the WS form of ntm_seq_bwd.hip):
+    stream waves carry the h part of the recurrent products from one step into the next, primed before the first step and
+    drained after the last.  Their edges -- a one-step sequence (what NTMCell.__call__ launches), a non-trivial initial state,
+    a gradient of the FINAL state -- against round 2's kernels (NTK_NTM_*_FORM=res) on the same inputs: every output, every
+    record, the state gradient and the weight gradients agree to float32 rounding (the summation order of a gate differs)."""
+    kw = CASES[0][1]
+    cfg, params, rng = _mk(kw, 514, 2, seed=41, scale=0.2)
+    B = 3
+    cell = _cell(cfg, params, cuda)
+    x = torch.from_numpy(rng.standard_normal((B, S, 514)).astype(np.float32)).to(cuda)
+    X = cell._pad_inputs(x)
+    st = {k: torch.from_numpy((v + rng.uniform(0, 0.1, size=v.shape)).astype(np.float32)).to(cuda) for k, v in O.zero_state(cfg, params, B).items()}
+    dlog = torch.from_numpy(rng.standard_normal((B, S, 2)).astype(np.float32)).to(cuda)
+    dfin = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32) * 0.1).to(cuda) for k, v in st.items()}
+    res = {}
+    for form in ("res", "ws"):
+        monkeypatch.setenv("NTK_NTM_FWD_FORM", form)
+        monkeypatch.setenv("NTK_NTM_BWD_FORM", form)
+        logits, outs, new, rec = cell.run_sequence(X, st, record=True)
+        g0 = cell.backward_sequence(X, st, rec, dlog, dfinal=dfin)
+        torch.cuda.synchronize()
+        res[form] = dict(logits=logits.clone(), outs=outs.clone(), grad=cell.params.grad.clone(),
+                         **{"new_" + k: v.clone() for k, v in new.items()}, **{"g0_" + k: v.clone() for k, v in g0.items()},
+                         **{"rec_" + k: rec[k].clone() for k in ("gates", "c", "u", "w", "M", "read")})
+    for k in res["res"]:
+        a, b = res["res"][k], res["ws"][k]
+        scale = float(a.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-6 * scale + 1e-7, (k, float((a - b).abs().max()), scale)
