@@ -28,13 +28,13 @@ import torch
 # counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv
 # (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
-TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": 8.7996e10 + 2.3872e10}
+TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": 9.0467e10 + 2.3860e10}
 TRUNK_TRAFFIC_PROFILE = {"direct": "profiles/r01_vgg_trunk_hbm_traffic_pmc.csv", "winograd2": "profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv",
-                         "winograd": "profiles/r03_vgg_trunk_wino43d_hbm_traffic_pmc.csv"}
+                         "winograd": "profiles/r04_vgg_trunk_blocked_hbm_traffic_pmc.csv"}
 # fraction of the direct-convolution multiplies the Winograd layers execute on the MFMA pipe: F(2x2,3x3) 16 per 2x2 tile
 # where the direct form has 36; F(4x4,3x3) 36 per 4x4 tile where it has 144
 WINO_EXECUTED_FRACTION = {"winograd": 36.0 / 144.0, "winograd2": 16.0 / 36.0}
-NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.445e8 + 1.036e9     # profiles/r02_ntm_seq_hbm_traffic_pmc.csv
+NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.448e8 + 1.036e9     # profiles/r04_ntm_seq_hbm_traffic_pmc.csv (FETCH_SIZE KB x 1024 x 2 + WRITE_SIZE KB x 1024)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
@@ -202,7 +202,7 @@ def cpu_baseline(ws, n_vgg_frames=8, T=20, model="ntm", dnc_shape=(256, 64)):
 # HBM-side bytes of the DNC cluster kernels at configs[2] (B 32, S 1300): profiles/r02_dnc_cluster_hbm_traffic_pmc.csv
 DNC_FWD_TRAFFIC_BYTES_B32_S1300 = 4.56e9        # inference-mode forward (2 x FETCH_SIZE + WRITE_SIZE)
 DNC_BWD_TRAFFIC_BYTES_B32_S1300 = 2.123e10
-NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.950e9 + 0.162e9   # profiles/r02_ntm_seq_hbm_traffic_pmc.csv
+NTM_BWD_TRAFFIC_BYTES_B32_S1300 = 0.950e9 + 0.162e9   # profiles/r04_ntm_seq_hbm_traffic_pmc.csv
 # HBM-side bytes per sequence-step of the memory-partitioned DNC cluster kernels at configs[4]'s shape (512 x 128, B 64):
 # profiles/r03_dnc_mp_hbm_traffic_pmc.csv (2 x FETCH_SIZE + WRITE_SIZE over B 64 x S 200): the inference-mode forward moves
 # 1.00 - 1.04x the algorithmic bytes (2 650 112 per sequence-step; two collections: 2 649 848 and 2 758 376 -- write-backs
@@ -246,11 +246,11 @@ def memory_step_probe(trk, model, gts0, offs, B, T):
         X, st0, logits, rec = trk.forward_features(fmap, gts0, record=True)
         _loss, _pred, dlogits = T_.offset_loss(logits, offs, T)
         ms_b = _median_ms(lambda: trk.cell.backward_sequence(X, st0, rec, dlogits))
-        kern, kern_b = "ntm_seq_fwd_kernel", "ntm_seq_bwd_kernel (+ 3 weight-gradient GEMMs)"
+        kern, kern_b = "ntm_seq_fwd_ws_kernel (benchmark shape; ntm_seq_fwd_kernel otherwise)", "ntm_seq_bwd_kernel, wave-specialised form at the benchmark shape (+ 3 weight-gradient GEMMs)"
         traffic = NTM_FWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)
         traffic_b = NTM_BWD_TRAFFIC_BYTES_B32_S1300 * (B * S) / (32.0 * 1300.0)
-        note = "serialise + input projection + persistent sequence kernel, one workgroup per sequence; state is LDS resident"
-        tnote = "PMC, profiles/r02_ntm_seq_hbm_traffic_pmc.csv: input projection read + per-step BPTT records; the memory state itself never leaves LDS"
+        note = "serialise + input projection + persistent sequence kernel, one workgroup per sequence; state is LDS resident; the h part of the recurrent weight stream runs on stream waves beside the step (DESIGN.md 4.2')"
+        tnote = "PMC, profiles/r04_ntm_seq_hbm_traffic_pmc.csv: input projection read + per-step BPTT records; the memory state itself never leaves LDS"
     else:
         c = trk.core
         per_step = 2 * c.N * c.W * 4 + 2 * c.Wn * c.N * c.N * 4 + 2 * (c.R + c.Wn) * c.N * 4 + 2 * c.Wn * c.N * 4 + 2 * c.N * 4
