@@ -546,10 +546,12 @@ def main():
         # event time `ntm_fwd_bwd_opt_stream` also contains the core stream's wait for its features when the trunk is the bound
         core_ms = out["memory_step"]["ms"] + (out["memory_step_bptt"]["ms"] if args.mode == "train" else 0.0)
         cu_trunk, cu_core = trunk_alone * 1e-3 * cus, core_ms * 1e-3 * min(core_wgs, cus)
+        serial = bool(getattr(trk, "serial_trunk", False))          # trunk and core on ONE stream (a cooperative core over every CU): nothing overlaps
         out["breakdown_ms"]["trunk_alone"] = round(trunk_alone, 3)
         out["breakdown_ms"]["cu_seconds"] = {
             "trunk": round(cu_trunk, 3), "core": round(cu_core, 3), "compute_units": cus, "core_workgroups": core_wgs,
-            "cu_time_bound_ms": round((cu_trunk + cu_core) / cus * 1e3, 3),
+            "cu_time_bound_ms": None if serial else round((cu_trunk + cu_core) / cus * 1e3, 3),
+            "schedule": "serial: trunk pass and core pass alternate on one stream" if serial else "overlapped: the trunk pass of batch i + 1 runs beside the core pass of batch i",
             "note": "trunk = the trunk pass alone on the idle device x every CU (its grids fill the chip); core = the recurrent forward + "
                     "BPTT kernels alone (memory_step.ms + memory_step_bptt.ms) x the CUs their persistent workgroups hold; "
                     "cu_time_bound_ms = (trunk + core) / CUs: what the step cannot beat while both streams overlap"}
