@@ -265,8 +265,9 @@ class VGG16Conv43(object):
         # the benchmark computes the whole map, as the reference graph does.
         self.features_window = None
         # parts / streams of a trunk pass (see __call__): two for the default F(4x4) fp32 trunk; measured a loss for the direct
-        # kernels (149 -> 173 ms per step) and for the bf16 trunk (59.5 -> 59.9), no change for F(2x2)
-        self.split_streams = int(os.environ.get("NTK_TRUNK_SPLIT", "2" if (dtype == "f32" and algo == "winograd") else "1"))
+        # kernels (149 -> 173 ms per step) and for round 2's bf16 tile kernel (59.5 -> 59.9), no change for F(2x2); the bf16 patch-form
+        # kernel (one workgroup per CU, like the F(4x4) kernel) gains 2 % (640 frames: 18.07 -> 17.67 ms)
+        self.split_streams = int(os.environ.get("NTK_TRUNK_SPLIT", "2" if ((dtype == "f32" and algo == "winograd") or dtype == "bf16") else "1"))
         self._side = []
         # fp32 trunk: "winograd" = fused Winograd F(4x4,3x3) wherever the layer shape allows (conv1_2 .. conv4_3 on
         # 224x224 frames; 4x fewer multiplies than the direct form, error ~1e-5 of the activation scale per layer),
