@@ -226,6 +226,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if constexpr (POOL) opix[tm] = fq < 0 ? -1 : ((fq * (H >> 1) + (Y >> 1)) * (W >> 1) + (X >> 1));
         else opix[tm] = fq < 0 ? -1 : ((fq * H + Y) * W + X);
     }
+    // LDS byte offsets (inside patch buffer 0) of this lane's A-operand fragments, per tap and tile, for the first 16-channel half of a
+    // chunk (the second half is the same address with bit 5 flipped: the other slot pair of the pixel's 64-byte row).  They are the same
+    // in every chunk, so they are computed ONCE and toggled between the two patch buffers per chunk: recomputed per step (pixel shift,
+    // swizzle, scale: ~5 vector instructions per fragment) they were most of what the fragment reads cost beside the MFMAs.
+    int xa[9][TM];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int p = pix0[tm] + (tap / 3 - 1) * PW + (tap % 3 - 1);
+            xa[tap][tm] = p * PIXB + ((kh ^ p_sw<PIECES>(p)) << 4);
+        }
     f32x16 acc[TM][2];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][nt][r] = 0.f;
     // weight fragment: row n = wn * 64 + nt * 32 + mcol of tap dx, piece 2 k16 + kh
-    const int bn0 = (wn * 64 + mcol) * PIXB, bsw = p_sw<PIECES>(mcol);
+    const int wa0 = 2 * ABYTES + (wn * 64 + mcol) * PIXB + ((kh ^ p_sw<PIECES>(mcol)) << 4);        // byte offset in s_mem, weight buffer 0
 
     // ---- prologue: patch of chunk 0 and the first stage of weights
     dma_patch(0, 0, 0, NPAW);
@@ -264,8 +276,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (more_p) dma_patch1(chunk + 1, abuf ^ 1, std::integral_constant<int, part * NDP + (k - NDW)>{});
             }
         };
-        const unsigned char* Ab = s_A[abuf];
-        const unsigned char* Bb = s_B[bbuf];
+        const int wa = wa0 + bbuf * SBYTES;
         // the stage's STAPS * K16 steps (tap, 16-channel half), software-pipelined: the fragments of step i + 1 are requested
         // before the MFMAs of step i (left to itself the compiler reads every fragment right in front of its first MFMA and
         // waits for it there: four exposed LDS round trips per eight MFMAs)
@@ -274,15 +285,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         auto load_frags = [&](auto stc, f32x4 (&wfs)[2], f32x4 (&xfs)[TM]) {
             constexpr int st = decltype(stc)::value, dxi = st / K16, k16 = st % K16;      // dxi: tap inside the stage
             constexpr int tap = part * STAPS + dxi;
-            constexpr int shift = (tap / 3 - 1) * PW + (tap % 3 - 1);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                wfs[nt] = *reinterpret_cast<const f32x4*>(Bb + (dxi * BN + nt * 32) * PIXB + bn0 + (((2 * k16 + kh) ^ bsw) << 4));
+                wfs[nt] = *reinterpret_cast<const f32x4*>(s_mem + ((wa ^ (k16 << 5)) + (dxi * BN + nt * 32) * PIXB));
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int p = pix0[tm] + shift;
-                xfs[tm] = *reinterpret_cast<const f32x4*>(Ab + p * PIXB + (((2 * k16 + kh) ^ p_sw<PIECES>(p)) << 4));
-            }
+            for (int tm = 0; tm < TM; ++tm) xfs[tm] = *reinterpret_cast<const f32x4*>(s_mem + (xa[tap][tm] ^ (k16 << 5)));
         };
         auto step = [&](auto stc) {
             constexpr int st = decltype(stc)::value;
@@ -310,16 +317,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
     for (int chunk = 0; chunk < NC; ++chunk) {
-        // opaque copies of the per-lane bases: the 72 fragment addresses of a chunk are the same in every chunk, and hoisted out of
-        // this loop they cost more registers than the kernel has left (they went to scratch, and a scratch reload waits for every
-        // DMA in flight)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(pix0[tm]));
         stage_body(chunk, std::integral_constant<int, 0>{});
         if constexpr (SPC > 1) {
             stage_body(chunk, std::integral_constant<int, 1>{});
             stage_body(chunk, std::integral_constant<int, 2>{});
         }
+        const int flip = (chunk & 1) ? -ABYTES : ABYTES;                        // the next chunk's patch is in the other buffer
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) xa[tap][tm] += flip;
     }
 
     // ---- epilogue: register r of acc[tm][nt] = channel nt * 32 + 8 (r >> 2) + 4 kh + (r & 3) of this lane's pixel
