@@ -83,6 +83,19 @@ int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_packed_bf16p, 
 int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, const float* bias, void* out_bf16,
                                      int frames, int H, int W, int cin, int cout, void* stream);
 
+/* The SPLIT form of the fp32 trunk (csrc/conv_bf16p.hip, template flag X3; round 4): the same fp32 operator (vgg.py:155-161) on the
+ * bf16 matrix pipe.  Every fp32 value v travels as hi = bf16(v), lo = bf16(v - hi); a product x w is accumulated in fp32 as
+ * xh wh + xh wl + xl wh (relative error of the split 2^-17: per layer 4e-6 .. 5e-6 of the activation scale, what the F(4x4) Winograd
+ * kernel has).  A split map is [frames][H][W][C / 16][2][16] bf16 (hi x16 | lo x16 per group of 16 channels: the bytes of the fp32 map).
+ * Shapes: H, W multiples of 8, or W = 28 with H a multiple of 4 and no pool; cin a multiple of 16, cout of 64.  Packed weights:
+ * 18 * cin * cout bf16 elements, packed per layer and frame shape.  out_f32 = 1 writes fp32 NHWC (where the trunk leaves the split
+ * form); in_f32 = 1 reads an fp32 NHWC map and splits it while staging (where the trunk enters it: cin <= 64 and cout = 64 only). */
+size_t ntk_vgg_split3_packed_elems(int cin, int cout);
+int ntk_vgg_split3_supported(int H, int W, int cin, int cout, int fuse_pool);
+int ntk_vgg_pack_weights_split3(const float* w_hwio, void* w_packed, int cin, int cout, int H, int W, void* stream);
+int ntk_vgg_conv3x3_relu_split3(const void* in_split, const void* w_packed, const float* bias, void* out,
+                                int frames, int H, int W, int cin, int cout, int fuse_pool, int in_f32, int out_f32, void* stream);
+
 /* The same operator by fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (2.25x fewer multiplies; results equal to
  * ntk_vgg_conv3x3_relu_f32 up to rounding, ~1e-6 relative per layer).  Weights: U = G g G^T for the 16 transform
  * planes, packed lane-major for the MFMA B operand (ntk_vgg_wino_packed_floats(cin, cout) = 16*cin*cout floats).

@@ -35,6 +35,10 @@ def _sig(lib):
         "ntk_vgg_bf16p_supported": (c_int, [c_int] * 5),
         "ntk_vgg_pack_weights_bf16p": (c_int, [P, P] + [c_int] * 4 + [P]),
         "ntk_vgg_conv3x3_relu_bf16p": (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+        "ntk_vgg_split3_packed_elems": (c_size_t, [c_int, c_int]),
+        "ntk_vgg_split3_supported": (c_int, [c_int] * 5),
+        "ntk_vgg_pack_weights_split3": (c_int, [P, P] + [c_int] * 4 + [P]),
+        "ntk_vgg_conv3x3_relu_split3": (c_int, [P, P, P, P] + [c_int] * 8 + [P]),
         "ntk_gemm_nt_f32": (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
         "ntk_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
         "ntk_gemm_tn_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -71,6 +71,24 @@ __device__ __forceinline__ pbf16x8 p_as_bf16x8(const f32x4& v) {
     return u.b;
 }
 
+typedef _Float16 ph16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ph16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ph16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ph16x8 p_as_f16x8(const f32x4& v) {
+    union { f32x4 f; ph16x8 h; } u;
+    u.f = v;
+    return u.h;
+}
+// The split form's two parts of four fp32 values: hi = fp16(v) rounded TOWARD ZERO (v_cvt_pkrtz_f16_f32: a value beyond the fp16
+// range saturates at 65504 instead of becoming infinite, and lo then carries the rest up to 131008), lo = fp16(v - hi) rounded to
+// nearest: v = hi + lo to 2^-22 |v| (eleven + eleven bits) for 6e-5 < |v| < 65504; below, to fp16's absolute 6e-8.
+__device__ __forceinline__ void s3_split4(const f32x4& v, ph16x4& hi, ph16x4& lo) {
+    const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    hi = ph16x4{(_Float16)h01[0], (_Float16)h01[1], (_Float16)h23[0], (_Float16)h23[1]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lo[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e] - (float)hi[e], -65504.f, 65504.f);      // (saturating as well)
+}
+
 // 16-byte piece `piece` of LDS pixel / column `idx` lives in slot piece ^ sw(idx): PIECES = 4 (64-byte rows): bits 2..3 of the
 // index; PIECES = 2 (32-byte rows): bit 3 -- sixteen consecutive indices then cover all 64 banks once per ds_read_b128 group
 template <int PIECES>
@@ -97,12 +115,76 @@ __global__ void bf16p_pack_kernel(const float* __restrict__ w, __bf16* __restric
     }
 }
 
+// The SPLIT form's weights (X3 below): a 32-"channel" chunk = 16 real input channels, pieces 0, 1 = the fp16 HIGH parts of channels
+// 0..7 / 8..15, pieces 2, 3 = the fp16 LOW parts (w - high, rounded to fp16) of the same channels.  Same stage order as above.
+// The weights are scaled by a power of two first (exact) so that the largest is in [2^13, 2^14): the low parts are then normal fp16
+// numbers down to weights 2^-17 of the largest.  The inverse scale sits behind the packed image (tail[0]); the kernel's epilogue
+// multiplies by it (exact).  Two launches: the maximum (as its bit pattern: positive floats order as integers), then the packing.
+__global__ void split3_absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ tail) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(w[i]);
+        if (v < 3.0e38f) m = fmaxf(m, v);                                       // not-a-number and infinite weights do not set the scale
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(tail + 1, __float_as_uint(m));
+}
+__global__ void split3_scale_kernel(unsigned* __restrict__ tail) {
+    const float m = __uint_as_float(tail[1]);
+    int e = 0;
+    if (m > 0.f) frexpf(m, &e);                                                 // m = f * 2^e, f in [0.5, 1)
+    int k = 14 - e;                                                             // m * 2^k in [2^13, 2^14)
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    reinterpret_cast<float*>(tail)[0] = ldexpf(1.f, -k);                        // what the convolution multiplies its sums by
+    reinterpret_cast<float*>(tail)[2] = ldexpf(1.f, k);                         // what the packing multiplies the weights by
+}
+template <int BN>
+__global__ void split3_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wq, int Cin, int Cout) {
+    const size_t total = (size_t)18 * Cin * Cout;
+    const float wscale = reinterpret_cast<const float*>(wq + total)[2];
+    const int NC = Cin / 16;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx & 7;
+        size_t r = idx >> 3;
+        const int slot = (int)(r & 3); r >>= 2;
+        const int n = (int)(r % BN); r /= BN;
+        const int tap = (int)(r % 9); r /= 9;
+        const int chunk = (int)(r % NC);
+        const int cb = (int)(r / NC);
+        const int piece = slot ^ p_sw<4>(n);
+        const int c = chunk * 16 + (piece & 1) * 8 + e;
+        const float v = w[((size_t)tap * Cin + c) * Cout + (size_t)cb * BN + n] * wscale;
+        const _Float16 hi = (_Float16)v;
+        wq[idx] = (piece & 2) ? (_Float16)(v - (float)hi) : hi;
+    }
+}
+
 // NW: waves per workgroup.  8: 512 output pixels, one workgroup per CU.  4 (64 columns only): 256 pixels and under 80 KB of LDS,
 // TWO workgroups per CU -- for the layers with few stages (64 input channels: six), where a workgroup's prologue (the first patch
 // and weights have to land before the first MFMA) and epilogue are a third of its life and nothing else overlaps them.
-template <int BN, int TW, int TH, int NSUB, int KC, bool POOL, bool OUTF32, int NW = 8>
+//
+// X3 -- the SPLIT form: an fp32 convolution on the 16-bit matrix pipe.  Every fp32 value v is carried as two fp16 numbers, hi = fp16(v)
+// and lo = fp16(v - hi) (v = hi + lo to 2^-22 |v|: s3_split4), and a product x w is accumulated as xh wh + xh wl + xl wh in fp32 (the
+// dropped xl wl is 2^-20 relative): three v_mfma_f32_32x32x16_f16 where the fp32 pipe needs sixteen times the cycles of one.  Maps are
+// [pixel][C / 16][hi x16 | lo x16] fp16 (the bytes of an fp32 map); to this kernel that is an NHWC 16-bit map of 2 C channels in
+// 32-channel chunks, so the staging is the bf16 form's, byte for byte.  (First built with bf16 parts: 2^-17 per product, 1.5e-5 of the
+// activation scale through the trunk -- four times the F(4x4) Winograd kernel's error; fp16 parts cost the same and give 2^-20.  fp16's
+// narrow exponent is handled on both sides: weights are scaled by a power of two when packed, activations saturate instead of
+// overflowing.)  A "step" becomes a tap: 24 MFMAs per wave on four fragment
+// sets (xh, xl, wh, wl), the three products of a tap software-pipelined against each other's fragment reads.
+// LIN: sub-blocks of TW x TH pixels whose width is not a power of two (28 x 4: the 28 x 28 maps of conv4_x); tiles are then cut from
+// the workgroup's pixels in linear order (a tile may span two sub-blocks) and the last PNT * 32 - NSUB * TW * TH pixels are padding.
+// INF32 (split form, four-wave workgroups): the input is an fp32 NHWC map and the STAGING splits it -- 16-byte pieces through registers
+// (two or three per lane and stage, requested at the top of a stage, split and written to the patch image at its end) instead of DMA.
+// That is how the trunk enters the split form: conv1_1 keeps its fp32 kernel and conv1_2 reads its map as it is.
+template <int BN, int TW, int TH, int NSUB, int KC, bool POOL, bool OUTF32, int NW = 8, bool X3 = false, bool INF32 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_relu_bf16p_kernel(Bf16pArgs a) {
+    static_assert(!INF32 || (X3 && NW == 4), "fp32 input: split form on four waves (the eight-wave form has no registers for the staging)");
     constexpr int PNT = 2 * NW;                                                 // 32-pixel tiles per workgroup
+    constexpr bool LIN = (TW & (TW - 1)) != 0;
+    static_assert(!X3 || KC == 32, "split form: 16 real channels = one 32-channel chunk");
+    static_assert(!LIN || !POOL, "linear tiles have no row pairs");
     static_assert(NW == 8 || (NW == 4 && BN == 64), "four-wave workgroups take 64 columns");
     constexpr int PW = TW + 2, PH = TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
     constexpr int PIXB = KC * 2, PIECES = KC / 8, PPP = 1024 / PIXB;            // bytes per pixel row, 16-B pieces per row, rows per DMA
@@ -116,13 +198,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int TM = BN == 128 ? 4 : 2;                                       // pixel tiles per wave (two column tiles either way)
     constexpr int TPS = (TW * TH) / 32;                                         // tiles per sub-block (0: two sub-blocks per tile)
     constexpr int K16 = KC / 16;
-    static_assert(NSUB * TW * TH == 32 * PNT, "512 (256) output pixels per workgroup");
+    static_assert(LIN ? NSUB * TW * TH <= 32 * PNT : NSUB * TW * TH == 32 * PNT, "512 (256) output pixels per workgroup");
     constexpr int TRB = POOL ? 0 : NW * TM * 32 * 144;                           // the un-pooled epilogue's transpose image (below)
     constexpr int LDSB = (2 * ABYTES + 2 * SBYTES) > TRB ? (2 * ABYTES + 2 * SBYTES) : TRB;
     static_assert(LDSB + 1024 <= (NW == 8 ? 160 : 80) * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char s_mem[LDSB];
-    unsigned char (*s_A)[ABYTES] = reinterpret_cast<unsigned char (*)[ABYTES]>(s_mem);
-    unsigned char (*s_B)[SBYTES] = reinterpret_cast<unsigned char (*)[SBYTES]>(s_mem + 2 * ABYTES);
+    // s_mem: two patch buffers of ABYTES, then two weight-stage buffers of SBYTES
     __shared__ int s_sbf[NSUB], s_sby[NSUB], s_sbx[NSUB];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -172,6 +253,37 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 aoff[i] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + (slot ^ p_sw<PIECES>(lp)) * 8) * sizeof(__bf16));
         }
     }
+    // INF32: item it = tid + 64 NW i = (patch pixel it / 4, channel quad it % 4): 16 bytes of the fp32 map -> 8 bytes of high parts in
+    // piece (q >> 1) of the pixel's row and 8 bytes of low parts in piece 2 + (q >> 1) (= the same byte address with bit 5 flipped)
+    constexpr int NIT = INF32 ? (NPX * 4 + 64 * NW - 1) / (64 * NW) : 1;       // items per lane and chunk
+    constexpr int NITS = (NIT + SPC - 1) / SPC;                                  // ... and stage
+    unsigned foff[NIT];
+    int fdst[NIT];
+    if constexpr (INF32) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = tid + 64 * NW * i, lp = it >> 2, qd = it & 3;
+            foff[i] = 0x80000000u; fdst[i] = -1;
+            if (lp < NPX) {
+                fdst[i] = lp * PIXB + (((qd >> 1) ^ p_sw<PIECES>(lp)) << 4) + (qd & 1) * 8;
+                const int q = lp / SPX, rem = lp - q * SPX;
+                const int py = rem / PW, px = rem - py * PW;
+                const int fq = s_sbf[q];
+                const int y = s_sby[q] - 1 + py, x = s_sbx[q] - 1 + px;
+                if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W)
+                    foff[i] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin) * sizeof(__bf16) + qd * 16);   // Cin bf16 = Cin / 2 floats
+            }
+        }
+    }
+    auto f32_rsrc = [&](int chunk) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pin + (size_t)chunk * KC), 0, (int)(in_bytes - (unsigned)chunk * PIXB), 0x00020000);
+    };
+    auto f32_put = [&](const f32x4& v, int dst) {                               // split one item into the patch image at byte dst of s_mem
+        ph16x4 h, l;
+        s3_split4(v, h, l);
+        *reinterpret_cast<ph16x4*>(s_mem + dst) = h;
+        *reinterpret_cast<ph16x4*>(s_mem + (dst ^ 32)) = l;
+    };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)s_mem;       // LDS byte address of the block
     auto dma_patch = [&](int chunk, int buf, int i0, int i1) {                 // pieces i0 .. i1 - 1 of this wave
         const pv4i rs = p_rsrc(pin + (size_t)chunk * KC, in_bytes - (unsigned)chunk * PIXB);
@@ -207,21 +319,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // patch pixel (tap 0,0 = the output pixel itself, halo offset included) of this lane's column in each of its tiles
     int pix0[TM];
     int opix[TM];                                                               // output pixel (element offset / Cout) or -1
+    // column m of tile t -> sub-block q and pixel (y, x) inside it; false: a padding column (LIN only)
+    auto tile_pixel = [&](int t, int m, int& q, int& y, int& x) -> bool {
+        if constexpr (LIN) {
+            const int lin = t * 32 + m;
+            if (lin >= NSUB * TW * TH) { q = 0; y = 0; x = 0; return false; }
+            q = lin / (TW * TH);
+            const int rem = lin - q * (TW * TH);
+            y = rem / TW; x = rem - y * TW;
+        } else if constexpr (TPS == 0) {                                        // 4x4 sub-blocks: two per tile
+            q = 2 * t + (m >> 4); y = (m >> 2) & 3; x = m & 3;
+        } else {
+            constexpr int RPT = 32 / TW;                                        // rows of a sub-block per tile
+            const int tl = t % TPS, j = m / TW;
+            q = t / TPS;
+            y = 2 * ((tl >> 1) * RPT + j) + (tl & 1);                           // rows y, y + 1 sit in consecutive tiles (the pool's pairs)
+            x = m % TW;
+        }
+        return true;
+    };
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int t = wm * TM + tm;
         int q, y, x;
-        if constexpr (TPS == 0) {                                               // 4x4 sub-blocks: two per tile
-            q = 2 * t + (mcol >> 4); y = (mcol >> 2) & 3; x = mcol & 3;
-        } else {
-            constexpr int RPT = 32 / TW;                                        // rows of a sub-block per tile
-            const int tl = t % TPS, j = mcol / TW;
-            q = t / TPS;
-            y = 2 * ((tl >> 1) * RPT + j) + (tl & 1);                           // rows y, y + 1 sit in consecutive tiles (the pool's pairs)
-            x = mcol % TW;
-        }
+        const bool real = tile_pixel(t, mcol, q, y, x);
         pix0[tm] = q * SPX + (y + 1) * PW + (x + 1);
-        const int fq = s_sbf[q];
+        const int fq = real ? s_sbf[q] : -1;
         const int Y = s_sby[q] + y, X = s_sbx[q] + x;
         if constexpr (POOL) opix[tm] = fq < 0 ? -1 : ((fq * (H >> 1) + (Y >> 1)) * (W >> 1) + (X >> 1));
         else opix[tm] = fq < 0 ? -1 : ((fq * H + Y) * W + X);
@@ -249,7 +372,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int wa0 = 2 * ABYTES + (wn * 64 + mcol) * PIXB + ((kh ^ p_sw<PIECES>(mcol)) << 4);        // byte offset in s_mem, weight buffer 0
 
     // ---- prologue: patch of chunk 0 and the first stage of weights
-    dma_patch(0, 0, 0, NPAW);
+    if constexpr (INF32) {
+        const __amdgpu_buffer_rsrc_t rs = f32_rsrc(0);
+        f32x4 v[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)foff[i], 0, 0));
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            if (fdst[i] >= 0) f32_put(v[i], fdst[i]);
+    } else {
+        dma_patch(0, 0, 0, NPAW);
+    }
     dma_weights(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -267,7 +400,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // they stop both waves of every SIMD at once (ablation: 24 % of the kernel); behind eight queued MFMAs the other wave
         // of the SIMD has the pipe meanwhile.
         constexpr int NDW = (NPB + NW - 1) / NW;                                 // weight pieces per wave and stage
-        constexpr int NDP = (NPAW + SPC - 1) / SPC;                              // patch pieces per wave and stage
+        constexpr int NDP = INF32 ? 0 : (NPAW + SPC - 1) / SPC;                  // patch pieces per wave and stage
         const bool more_w = !(BF16P_ABL & 1) && s + 1 < NSTG, more_p = !(BF16P_ABL & 1) && chunk + 1 < NC;
         auto dma_slot = [&](auto kc) {                                           // k-th DMA of this stage
             constexpr int k = decltype(kc)::value;
@@ -277,9 +410,87 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         };
         const int wa = wa0 + bbuf * SBYTES;
+        f32x4 fst[NITS];                                                         // INF32: this stage's share of the next chunk's patch
+        if constexpr (INF32) {
+            const __amdgpu_buffer_rsrc_t rs = f32_rsrc(more_p ? chunk + 1 : chunk);
+#pragma unroll
+            for (int j = 0; j < NITS; ++j)
+                if (part * NITS + j < NIT) fst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)foff[part * NITS + j], 0, 0));
+        }
         // the stage's STAPS * K16 steps (tap, 16-channel half), software-pipelined: the fragments of step i + 1 are requested
         // before the MFMAs of step i (left to itself the compiler reads every fragment right in front of its first MFMA and
         // waits for it there: four exposed LDS round trips per eight MFMAs)
+        if constexpr (X3) {
+            // tap by tap: A = wh xh, B = wl xh, C = wh xl, eight MFMAs each.  wl is requested in front of A's MFMAs, xl in front of
+            // B's, the next tap's wh and xh (xh's registers are free once B has issued) in front of C's: every fragment read has at
+            // least eight MFMAs (256 cycles) of the wave's own work in front of its first use.
+            f32x4 wh[2][2], wl[2], xh[TM], xl[TM];
+            auto ld_w = [&](auto dc, auto kc, f32x4 (&w)[2]) {
+                constexpr int dxi = decltype(dc)::value, k16 = decltype(kc)::value;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    w[nt] = *reinterpret_cast<const f32x4*>(s_mem + ((wa ^ (k16 << 5)) + (dxi * BN + nt * 32) * PIXB));
+            };
+            auto ld_x = [&](auto dc, auto kc, f32x4 (&x)[TM]) {
+                constexpr int tap = part * STAPS + decltype(dc)::value, k16 = decltype(kc)::value;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) x[tm] = *reinterpret_cast<const f32x4*>(s_mem + (xa[tap][tm] ^ (k16 << 5)));
+            };
+            auto mm = [&](const f32x4 (&w)[2], const f32x4 (&x)[TM]) {
+                if constexpr ((BF16P_ABL & 8) != 0) return;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[tm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p_as_f16x8(w[nt]), p_as_f16x8(x[tm]), acc[tm][nt], 0, 0, 0);
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            constexpr int NSS = STAPS * 3;                                       // sub-steps of eight MFMAs
+            static_assert(NDW + NDP <= NSS, "one DMA per sub-step");
+            auto tapstep = [&](auto dc) {
+                constexpr int dxi = decltype(dc)::value;
+                if constexpr (!(BF16P_ABL & 4)) ld_w(dc, I1{}, wl);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wh[dxi & 1], xh);
+                dma_slot(std::integral_constant<int, 3 * dxi>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(BF16P_ABL & 4)) ld_x(dc, I1{}, xl);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wl, xh);
+                dma_slot(std::integral_constant<int, 3 * dxi + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (dxi + 1 < STAPS && !(BF16P_ABL & 4)) {
+                    ld_w(std::integral_constant<int, dxi + 1>{}, I0{}, wh[(dxi + 1) & 1]);
+                    ld_x(std::integral_constant<int, dxi + 1>{}, I0{}, xh);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mm(wh[dxi & 1], xl);
+                dma_slot(std::integral_constant<int, 3 * dxi + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            ld_w(I0{}, I0{}, wh[0]);
+            ld_x(I0{}, I0{}, xh);
+            if constexpr ((BF16P_ABL & 4) != 0) {                                // timing only: one fragment set per stage
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) { wh[1][nt] = wh[0][nt]; wl[nt] = wh[0][nt]; }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) xl[tm] = xh[tm];
+            }
+            bp_for<0, STAPS>(tapstep);
+            if constexpr (INF32) {
+                if (more_p) {
+#pragma unroll
+                    for (int j = 0; j < NITS; ++j)
+                        if (part * NITS + j < NIT && fdst[part * NITS + j] >= 0) f32_put(fst[j], (abuf ^ 1) * ABYTES + fdst[part * NITS + j]);
+                }
+            }
+            if (!(BF16P_ABL & 2)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            return;
+        }
         constexpr int NSTEP = STAPS * K16;
         f32x4 wf[2][2], xf[2][TM];
         auto load_frags = [&](auto stc, f32x4 (&wfs)[2], f32x4 (&xfs)[TM]) {
@@ -331,6 +542,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---- epilogue: register r of acc[tm][nt] = channel nt * 32 + 8 (r >> 2) + 4 kh + (r & 3) of this lane's pixel
     const int nbase = cb * BN + wn * 64 + 4 * kh;
+    float oscale = 1.f;                                                         // split form: the inverse of the weights' power-of-two scale
+    if constexpr (X3) oscale = *reinterpret_cast<const float*>(a.wq + (size_t)9 * Cin * Cout);
     if constexpr (POOL) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -344,11 +557,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float m2 = fmaxf(acc[tm][nt][4 * g + e], acc[tm + 1][nt][4 * g + e]);        // rows y, y + 1
-                        v[e] = fmaxf(fmaxf(m2, ntk_dpp<0xB1>(m2)) + bv[e], 0.f);                          // columns x, x ^ 1
+                        const float m4 = fmaxf(m2, ntk_dpp<0xB1>(m2));                                    // columns x, x ^ 1
+                        v[e] = fmaxf((X3 ? m4 * oscale : m4) + bv[e], 0.f);
                     }
                     if (opix[tm] >= 0 && (mcol & 1) == 0) {
                         if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)opix[tm] * Cout + n) = v;
-                        else {
+                        else if constexpr (X3) {                                // split map: [n / 16][hi x16 | lo x16]
+                            ph16x4 oh, ol;
+                            s3_split4(v, oh, ol);
+                            _Float16* op = reinterpret_cast<_Float16*>(a.out) + (size_t)opix[tm] * (2 * Cout) + (n >> 4) * 32 + (n & 15);
+                            *reinterpret_cast<ph16x4*>(op) = oh;
+                            *reinterpret_cast<ph16x4*>(op + 16) = ol;
+                        } else {
                             pbf16x4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
@@ -367,12 +587,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         constexpr int WREG = TM * 32 * RB;                                      // bytes per wave
         static_assert(NW * WREG <= LDSB, "the transpose image fits");
         unsigned char* tr = s_mem + wave * WREG;
-        constexpr int NPASS = OUTF32 ? 2 : 1;                                   // fp32 rows: one 32-column half at a time
+        constexpr bool WIDE = OUTF32 || X3;                                     // four bytes per channel: fp32, or a split map's hi + lo
+        constexpr int NPASS = WIDE ? 2 : 1;                                     // ... then one 32-column half at a time
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                if (OUTF32 && nt != ps) continue;
+                if (WIDE && nt != ps) continue;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + nbase + nt * 32 + 8 * g);
@@ -380,10 +601,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int tm = 0; tm < TM; ++tm) {
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[tm][nt][4 * g + e] + bv[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf((X3 ? acc[tm][nt][4 * g + e] * oscale : acc[tm][nt][4 * g + e]) + bv[e], 0.f);
                         unsigned char* row = tr + (tm * 32 + mcol) * RB;
                         if constexpr (OUTF32) *reinterpret_cast<f32x4*>(row + (8 * g + 4 * kh) * 4) = v;
-                        else {
+                        else if constexpr (X3) {                                // the half's two 16-channel groups: [hi x16 | lo x16] x 2
+                            ph16x4 oh, ol;
+                            s3_split4(v, oh, ol);
+                            unsigned char* pr = row + (g >> 1) * 64 + ((g & 1) * 8 + 4 * kh) * 2;
+                            *reinterpret_cast<ph16x4*>(pr) = oh;
+                            *reinterpret_cast<ph16x4*>(pr + 32) = ol;
+                        } else {
                             pbf16x4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
@@ -399,16 +626,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tr + (tmr * 32 + mr) * RB + piece * 16);
                 const int t = wm * TM + tmr;
                 int q, y, x;
-                if constexpr (TPS == 0) { q = 2 * t + (mr >> 4); y = (mr >> 2) & 3; x = mr & 3; }
-                else {
-                    constexpr int RPT = 32 / TW;
-                    const int tl = t % TPS, jj = mr / TW;
-                    q = t / TPS; y = 2 * ((tl >> 1) * RPT + jj) + (tl & 1); x = mr % TW;
-                }
-                const int fq = s_sbf[q];
+                const bool real = tile_pixel(t, mr, q, y, x);
+                const int fq = real ? s_sbf[q] : -1;
                 if (fq >= 0) {
                     const size_t op = ((size_t)(fq * H + s_sby[q] + y) * W + s_sbx[q] + x) * Cout + cb * BN + wn * 64;
                     if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + op + ps * 32 + piece * 4) = v;
+                    else if constexpr (X3) *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.out) + 2 * (op + ps * 32) + piece * 8) = v;
                     else *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.out) + op + piece * 8) = v;
                 }
             }
@@ -416,9 +639,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
-template <int BN, int KC, int NW>
+template <int BN, int KC, int NW, bool X3 = false, bool INF32 = false>
 int bf16p_launch(const Bf16pArgs& a0, int H, int W, int pool, int out_f32, hipStream_t st) {
     Bf16pArgs a = a0;
+    if constexpr (X3 && !INF32) {
+        if (W == 28 && H % 4 == 0 && !(H % 8 == 0 && W % 8 == 0)) {            // 28 x 4 sub-blocks, four per workgroup, linear tiles
+            if (pool || NW != 8) return NTK_ERR_UNSUPPORTED;
+            a.bxN = 1; a.byN = H / 4;
+            const long long NQ = (long long)a.frames * a.byN, NS = (NQ + 3) / 4;
+            a.NQ = (int)NQ; a.NS = (int)NS; a.nCB = a.Cout / BN;
+            long long slots;
+            if (a.nCB >= 8) slots = NS * (a.nCB / 8);
+            else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
+            const unsigned grid = (unsigned)(slots * 8);
+            if constexpr (NW == 8) {
+                if (out_f32) conv3x3_relu_bf16p_kernel<BN, 28, 4, 4, 32, false, true, 8, true><<<grid, 512, 0, st>>>(a);
+                else conv3x3_relu_bf16p_kernel<BN, 28, 4, 4, 32, false, false, 8, true><<<grid, 512, 0, st>>>(a);
+            }
+            return NTK_OK;
+        }
+    }
     // sub-block shape, eight waves (512 pixels): 0 = 32x16 x1, 1 = 16x16 x2, 2 = 8x8 x8, 3 = 4x4 x32 (KC 16 only: its patches are 2.25x the
     // pixels); four waves (256 pixels): 0 = 32x8 x1, 1 = 16x16 x1, 2 = 8x8 x4
     int shape;
@@ -438,11 +678,11 @@ int bf16p_launch(const Bf16pArgs& a0, int H, int W, int pool, int out_f32, hipSt
 #define BF16P_GO(TW_, TH_, NSUB_)                                                                                             \
     do {                                                                                                                      \
         if (pool) {                                                                                                           \
-            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, true, NW><<<grid, 64 * NW, 0, st>>>(a);     \
-            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, false, NW><<<grid, 64 * NW, 0, st>>>(a);            \
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, true, NW, X3, INF32><<<grid, 64 * NW, 0, st>>>(a);     \
+            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, true, false, NW, X3, INF32><<<grid, 64 * NW, 0, st>>>(a);            \
         } else {                                                                                                              \
-            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, true, NW><<<grid, 64 * NW, 0, st>>>(a);    \
-            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, false, NW><<<grid, 64 * NW, 0, st>>>(a);           \
+            if (out_f32) conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, true, NW, X3, INF32><<<grid, 64 * NW, 0, st>>>(a);    \
+            else conv3x3_relu_bf16p_kernel<BN, TW_, TH_, NSUB_, KC, false, false, NW, X3, INF32><<<grid, 64 * NW, 0, st>>>(a);           \
         }                                                                                                                     \
     } while (0)
     if constexpr (KC == 32 && NW == 8) {
@@ -531,5 +771,75 @@ extern "C" int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_pac
     else rc = bf16p_launch<64, 16, 8>(a, H, W, fuse_pool, out_f32, st);
     NTK_REQUIRE(rc == NTK_OK, rc, "ntk_vgg_conv3x3_relu_bf16p: no instantiation for this shape");
     NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_bf16p");
+    return NTK_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The SPLIT form (X3): the fp32 trunk on the bf16 matrix pipe.  Maps are "split" maps: [frames][H][W][C / 16][hi x16 | lo x16] bf16.
+// ---------------------------------------------------------------------------------------------------------------------------------
+static int split3_form(int H, int W, int cin, int cout, int pool, int* bn, int* nw) {
+    if ((H % 4) || (W % 4) || cin % 16 || cout % 64) return 0;
+    const bool rect = (W % 8 == 0 && H % 8 == 0);
+    if (!rect && (pool || W != 28)) return 0;
+    *nw = (rect && cin <= 64 && cout == 64) ? 4 : 8;
+    *bn = (*nw == 8 && cout % 128 == 0) ? 128 : 64;
+    const int nCB = cout / *bn;
+    if (!(nCB <= 8 ? (8 % nCB) == 0 : (nCB % 8) == 0)) return 0;
+    return 1;
+}
+
+extern "C" size_t ntk_vgg_split3_packed_elems(int cin, int cout) { return (size_t)18 * cin * cout + 8; }    // + 16 bytes: the scales
+
+extern "C" int ntk_vgg_split3_supported(int H, int W, int cin, int cout, int fuse_pool) {
+    int bn = 0, nw = 0;
+    return split3_form(H, W, cin, cout, fuse_pool, &bn, &nw);
+}
+
+// HWIO fp32 weights -> the stage images of ntk_vgg_conv3x3_relu_split3 (bf16 high and low parts; 18 cin cout elements)
+extern "C" int ntk_vgg_pack_weights_split3(const float* w_hwio, void* w_packed, int cin, int cout, int H, int W, void* stream) {
+    NTK_REQUIRE(w_hwio && w_packed, NTK_ERR_BAD_PTR, "ntk_vgg_pack_weights_split3: null pointer");
+    int bn = 0, nw = 0;
+    NTK_REQUIRE(split3_form(H, W, cin, cout, 0, &bn, &nw), NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_pack_weights_split3: cin=%d (multiple of 16) cout=%d (multiple of 64) H=%d W=%d", cin, cout, H, W);
+    _Float16* wq = reinterpret_cast<_Float16*>(w_packed);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* tail = reinterpret_cast<unsigned*>(wq + (size_t)18 * cin * cout);
+    if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return NTK_ERR_HIP;
+    split3_absmax_kernel<<<256, 256, 0, st>>>(w_hwio, (size_t)9 * cin * cout, tail);
+    split3_scale_kernel<<<1, 1, 0, st>>>(tail);
+    if (bn == 128) split3_pack_kernel<128><<<1024, 256, 0, st>>>(w_hwio, wq, cin, cout);
+    else split3_pack_kernel<64><<<1024, 256, 0, st>>>(w_hwio, wq, cin, cout);
+    NTK_CHECK_LAUNCH("ntk_vgg_pack_weights_split3");
+    return NTK_OK;
+}
+
+// conv3x3 SAME + bias + ReLU (+ 2x2 max-pool) of a split map (in_f32 = 1: of an fp32 NHWC map, split by the staging; the four-wave
+// form only); out: a split map (out_f32 = 0) or fp32 NHWC (out_f32 = 1)
+extern "C" int ntk_vgg_conv3x3_relu_split3(const void* in_split, const void* w_packed, const float* bias, void* out,
+                                           int frames, int H, int W, int cin, int cout, int fuse_pool, int in_f32, int out_f32, void* stream) {
+    NTK_REQUIRE(in_split && w_packed && bias && out, NTK_ERR_BAD_PTR, "ntk_vgg_conv3x3_relu_split3: null pointer");
+    NTK_REQUIRE(ntk_aligned16(in_split) && ntk_aligned16(w_packed) && ntk_aligned16(out) && ntk_aligned16(bias), NTK_ERR_BAD_PTR,
+                "ntk_vgg_conv3x3_relu_split3: pointers must be 16-byte aligned");
+    int bn = 0, nw = 0;
+    NTK_REQUIRE(frames > 0 && H > 0 && W > 0 && split3_form(H, W, cin, cout, fuse_pool, &bn, &nw), NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_split3: frames=%d H=%d W=%d cin=%d cout=%d pool=%d (H, W multiples of 8, or W = 28 and H a multiple "
+                "of 4 without the pool; cin a multiple of 16, cout of 64)", frames, H, W, cin, cout, fuse_pool);
+    NTK_REQUIRE((unsigned long long)2 * H * W * cin * 4 <= 0x7ffffff0ull && (long long)frames * H * W < (1ll << 31), NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_split3: frame too large for 32-bit offsets");
+    Bf16pArgs a;
+    a.in = reinterpret_cast<const __bf16*>(in_split); a.wq = reinterpret_cast<const __bf16*>(w_packed); a.bias = bias; a.out = out;
+    a.frames = frames; a.H = H; a.W = W; a.Cin = 2 * cin; a.Cout = cout;       // to the kernel: a bf16 map of 2 cin channels
+    a.bxN = a.byN = a.NQ = a.NS = a.nCB = 0;
+    int rc;
+    hipStream_t st = (hipStream_t)stream;
+    NTK_REQUIRE(!in_f32 || nw == 4, NTK_ERR_UNSUPPORTED,
+                "ntk_vgg_conv3x3_relu_split3: an fp32 input map is read by the four-wave form only (cin <= 64, cout = 64, H and W multiples of 8)");
+    if (nw == 4 && in_f32) rc = bf16p_launch<64, 32, 4, true, true>(a, H, W, fuse_pool, out_f32, st);
+    else if (nw == 4) rc = bf16p_launch<64, 32, 4, true>(a, H, W, fuse_pool, out_f32, st);
+    else if (bn == 128) rc = bf16p_launch<128, 32, 8, true>(a, H, W, fuse_pool, out_f32, st);
+    else rc = bf16p_launch<64, 32, 8, true>(a, H, W, fuse_pool, out_f32, st);
+    NTK_REQUIRE(rc == NTK_OK, rc, "ntk_vgg_conv3x3_relu_split3: no instantiation for this shape");
+    NTK_CHECK_LAUNCH("ntk_vgg_conv3x3_relu_split3");
     return NTK_OK;
 }

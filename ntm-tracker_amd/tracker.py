@@ -249,12 +249,12 @@ class NTMOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  num_layers=1, read_head_size=4, write_head_size=1, write_first=False, init_scale=0.05,
                  learning_rate=1e-4, decay=0.95, momentum=0.9, max_gradient_norm=5.0, feature_channels=512,
-                 device="cuda", seed=42, vgg_chunk_frames=1024, conv_dtype="f32", conv_algo="winograd", features_roi=False):
+                 device="cuda", seed=42, vgg_chunk_frames=1024, conv_dtype="f32", conv_algo=None, features_roi=False):
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
         self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
-        self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and conv_algo == "winograd"
+        self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and self.vgg.algo == "winograd"
         if self.features_roi:          # conv4_3 only where extract_features reads it (GRID_START .. GRID_START + (GRID_N - 1) * GRID_STEP), whole 4x4 tiles
             lo = (GRID_START // 4) * 4
             hi = ((GRID_START + (GRID_N - 1) * GRID_STEP) // 4 + 1) * 4
@@ -324,13 +324,13 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
     def __init__(self, batch_size, sequence_length, vgg_weights=None, mem_size=128, mem_dim=20, hidden_size=200,
                  read_head_size=4, write_head_size=1, clip_value=20, feature_channels=512, device="cuda", seed=42,
                  vgg_chunk_frames=1024, learning_rate=1e-4, optimizer_epsilon=1e-10, max_gradient_norm=50.0,
-                 conv_dtype="f32", conv_algo="winograd", features_roi=False):
+                 conv_dtype="f32", conv_algo=None, features_roi=False):
         from .dnc import DNC
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
         self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
-        self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and conv_algo == "winograd"
+        self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and self.vgg.algo == "winograd"
         if self.features_roi:          # conv4_3 only where extract_features reads it (GRID_START .. GRID_START + (GRID_N - 1) * GRID_STEP), whole 4x4 tiles
             lo = (GRID_START // 4) * 4
             hi = ((GRID_START + (GRID_N - 1) * GRID_STEP) // 4 + 1) * 4

@@ -235,6 +235,59 @@ def pack_weights_bf16p(w_hwio, H, W):
     return wp
 
 
+# ---- the SPLIT form of the fp32 trunk (csrc/conv_bf16p.hip, template flag X3): every fp32 value travels as two fp16 numbers
+def to_split(x):
+    """fp32 NHWC [F,H,W,C] (C a multiple of 16) -> split map [F,H,W,C/16,2,16] fp16, as the kernels' epilogues write it
+    (csrc/conv_bf16p.hip s3_split4): hi = fp16(x) rounded toward zero (saturating at 65504), lo = fp16(x - hi)."""
+    F, H, W, C = x.shape
+    t = x.clamp(-65504.0, 65504.0)
+    hi = t.to(torch.float16)                                  # round to nearest ...
+    over = hi.to(torch.float32).abs() > t.abs()               # ... stepped back where that rounded away from zero
+    hi_i = hi.view(torch.int16)
+    hi = torch.where(over, hi_i - 1, hi_i).view(torch.float16)    # (sign-magnitude: one ulp toward zero is bits - 1)
+    lo = (x - hi.to(torch.float32)).clamp(-65504.0, 65504.0).to(torch.float16)
+    return torch.stack((hi.view(F, H, W, C // 16, 16), lo.view(F, H, W, C // 16, 16)), dim=4).contiguous()
+
+
+def from_split(s):
+    """split map -> fp32 NHWC (hi + lo)."""
+    F, H, W, G = s.shape[:4]
+    return (s[:, :, :, :, 0].to(torch.float32) + s[:, :, :, :, 1].to(torch.float32)).reshape(F, H, W, G * 16)
+
+
+def split3_supported(H, W, cin, cout, fuse_pool=False):
+    return bool(_lib.lib().ntk_vgg_split3_supported(H, W, cin, cout, 1 if fuse_pool else 0))
+
+
+def pack_weights_split3(w_hwio, H, W):
+    kh, kw, cin, cout = w_hwio.shape
+    wp = torch.empty(_lib.lib().ntk_vgg_split3_packed_elems(cin, cout), device=w_hwio.device, dtype=torch.float16)
+    _lib.check(_lib.lib().ntk_vgg_pack_weights_split3(_lib.ptr(w_hwio.contiguous()), _lib.ptr(wp), cin, cout, H, W, _lib.stream()),
+               "ntk_vgg_pack_weights_split3")
+    return wp
+
+
+def conv3x3_relu_split3(x, w_packed, bias, cin, cout, fuse_pool=False, out_f32=False, out=None):
+    """split map [F,H,W,Cin/16,2,16] (or an fp32 NHWC map [F,H,W,Cin]: the kernel's staging splits it; cin <= 64 and cout == 64 only)
+    -> relu(conv3x3_same(x) + b) as a split map (or fp32 NHWC when out_f32): the fp32 product x w accumulated as
+    xh wh + xh wl + xl wh on the 16-bit matrix pipe (fp16 parts, fp32 accumulators)."""
+    F, H, W = x.shape[:3]
+    in_f32 = x.dtype == torch.float32
+    if in_f32:
+        if x.dim() != 4 or x.shape[3] != cin:
+            raise _lib.NtkError("conv3x3_relu_split3: expected an fp32 NHWC map of %d channels" % cin)
+    elif x.dim() != 6 or x.shape[3] * 16 != cin or x.dtype != torch.float16 or tuple(x.shape[4:]) != (2, 16):
+        raise _lib.NtkError("conv3x3_relu_split3: expected a split map of %d channels" % cin)
+    oh, ow = (H // 2, W // 2) if fuse_pool else (H, W)
+    if out is None:
+        out = (torch.empty((F, oh, ow, cout), device=x.device, dtype=torch.float32) if out_f32
+               else torch.empty((F, oh, ow, cout // 16, 2, 16), device=x.device, dtype=torch.float16))
+    _lib.check(_lib.lib().ntk_vgg_conv3x3_relu_split3(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out), F, H, W,
+                                                      cin, cout, 1 if fuse_pool else 0, 1 if in_f32 else 0, 1 if out_f32 else 0,
+                                                      _lib.stream()), "ntk_vgg_conv3x3_relu_split3")
+    return out
+
+
 def pack_weights_bf16(w_hwio):
     kh, kw, cin, cout = w_hwio.shape
     wp = torch.empty((cout, 9 * cin), device=w_hwio.device, dtype=torch.bfloat16)
@@ -251,13 +304,15 @@ class VGG16Conv43(object):
     conv1_1 reads the fp32 frames, conv4_3 writes fp32 for the memory cell).
     """
 
-    def __init__(self, weights, device="cuda", chunk_frames=1024, dtype="f32", algo="winograd"):
+    def __init__(self, weights, device="cuda", chunk_frames=1024, dtype="f32", algo=None):
         self.device = torch.device(device)
         self.chunk_frames = int(chunk_frames)
         if dtype not in ("f32", "bf16"):
             raise _lib.NtkError("VGG16Conv43: dtype must be 'f32' or 'bf16'")
-        if algo not in ("winograd", "winograd2", "direct"):
-            raise _lib.NtkError("VGG16Conv43: algo must be 'winograd', 'winograd2' or 'direct'")
+        if algo is None:                                        # the fp32 trunk's default form (NTK_TRUNK_ALGO overrides)
+            algo = os.environ.get("NTK_TRUNK_ALGO", "split3")
+        if algo not in ("split3", "winograd", "winograd2", "direct"):
+            raise _lib.NtkError("VGG16Conv43: algo must be 'split3', 'winograd', 'winograd2' or 'direct'")
         self.dtype = dtype
         # (y0, x0, y1, x1) in conv4_3 output pixels, multiples of 4, or None: compute conv4_3 only there (F(4x4) fp32 trunk).  The
         # tracker's extract_features reads 64 fixed points of the 28x28 map (rows / columns 6..20): window (4, 4, 24, 24) = 25
@@ -267,12 +322,21 @@ class VGG16Conv43(object):
         # parts / streams of a trunk pass (see __call__): two for the default F(4x4) fp32 trunk; measured a loss for the direct
         # kernels (149 -> 173 ms per step) and for round 2's bf16 tile kernel (59.5 -> 59.9), no change for F(2x2); the bf16 patch-form
         # kernel (one workgroup per CU, like the F(4x4) kernel) gains 2 % (640 frames: 18.07 -> 17.67 ms)
-        self.split_streams = int(os.environ.get("NTK_TRUNK_SPLIT", "2" if ((dtype == "f32" and algo == "winograd") or dtype == "bf16") else "1"))
+        self.split_streams = int(os.environ.get("NTK_TRUNK_SPLIT", "2" if ((dtype == "f32" and algo in ("winograd", "split3")) or dtype == "bf16") else "1"))
         self._side = []
         # fp32 trunk: "winograd" = fused Winograd F(4x4,3x3) wherever the layer shape allows (conv1_2 .. conv4_3 on
         # 224x224 frames; 4x fewer multiplies than the direct form, error ~1e-5 of the activation scale per layer),
         # "winograd2" = fused Winograd F(2x2,3x3) (2.25x fewer multiplies, error ~3e-7 per layer); the direct
         # implicit-GEMM kernel runs where neither applies (conv1_1, odd frame sizes) and everywhere with "direct"
+        # "split3" = the SPLIT form (csrc/conv_bf16p.hip X3: every fp32 product as three fp16 MFMA products of hi / lo parts, fp32
+        # accumulators) on conv1_2 .. split3_upto,
+        # the F(4x4) Winograd kernel on the layers after it (on the 28 x 28 maps of conv4_x the two are within 2 %).  conv1_1 keeps its
+        # fp32 kernel (conv1_2's staging splits its map), the last split layer writes fp32 NHWC for the Winograd layers.
+        self.split3 = (algo == "split3" and dtype == "f32")
+        self.split3_upto = os.environ.get("NTK_SPLIT3_UPTO", "conv4_3")
+        self._packed_split3 = {}
+        if self.split3:
+            algo = "winograd"                                # everything else (weights packed, layouts, fallbacks) as the Winograd trunk
         self.algo = algo
         # form of the F(4x4) kernel: None = the library's default (eight waves per workgroup); 4 = round 2's one-wave-per-SIMD kernel
         self.wino_waves = None
@@ -295,6 +359,8 @@ class VGG16Conv43(object):
             b = torch.as_tensor(b, dtype=torch.float32).to(self.device).contiguous()
             if tuple(w.shape) != (3, 3, cin, cout):
                 raise _lib.NtkError("%s: weight shape %s != (3,3,%d,%d)" % (name, tuple(w.shape), cin, cout))
+            if self.split3 and dtype == "f32" and cin % 16 == 0:
+                self._w_hwio[name] = w                     # packed per frame shape on first use
             if dtype == "bf16" and cin % 64 == 0:
                 self.packed[name] = (pack_weights_bf16(w), b)
                 self._w_hwio[name] = w                     # the patch-form kernel packs per frame shape, on first use
@@ -320,9 +386,66 @@ class VGG16Conv43(object):
                 key = (name, h % 8 == 0 and w % 8 == 0)
                 if key not in self._packed_bf16p:
                     self._packed_bf16p[key] = pack_weights_bf16p(self._w_hwio[name], h, w)
+                    torch.cuda.current_stream(frames.device).synchronize()    # packed once, read from every stream a pass runs on
                 x = conv3x3_relu_bf16p(x, self._packed_bf16p[key], b, cin, cout, fuse_pool=pool, out_f32=last, out=out if last else None)
             else:
                 x = conv3x3_relu_bf16(x, wp, b, cin, cout, fuse_pool=pool, out_f32=last, out=out if last else None)
+        return x
+
+    def _trunk_ws(self, frames):
+        """two ping-pong workspaces per (stream, chunk shape) for the maps between the layers, allocated once: a training loop then
+        makes no allocator calls in its trunk passes (the largest map, conv1_1's, is 12.8 MB per frame)"""
+        F, H, W, _ = frames.shape
+        key = (torch.cuda.current_stream(frames.device).cuda_stream, F, H, W)
+        ws = self._blocked_ws.get(key)
+        if ws is None:
+            if len(self._blocked_ws) >= 8:                        # shapes come and go (tests, online tracking): keep the table small
+                self._blocked_ws.clear()
+            ws = (torch.empty(F * H * W * 64, device=frames.device), torch.empty(F * (H // 2) * (W // 2) * 64, device=frames.device))
+            self._blocked_ws[key] = ws
+        return ws
+
+    def split3_trunk_supported(self, frames_shape):
+        F, H, W = frames_shape[:3]
+        return (self.wino_waves in (None, 8) and self.features_window is None and blocked_trunk_supported(F, H, W)
+                and split3_supported(H, W, 64, 64, True))
+
+    def _forward_chunk_split3(self, frames, out):
+        """conv1_1 (fp32 kernel) -> conv1_2 .. split3_upto in the split form -> the rest on the F(4x4) kernel with blocked maps."""
+        F, H, W, _ = frames.shape
+        ws = self._trunk_ws(frames)
+        wp, b = self.packed["conv1_1"]
+        x = conv3x3_relu(frames, wp, b, 3, 64, out=ws[0][:F * H * W * 64].view(F, H, W, 64))
+        names = [l[0] for l in VGG_LAYERS]
+        n_split = names.index(self.split3_upto) if self.split3_upto in names else 0
+        mode = "nhwc"                                            # what x is: fp32 "nhwc", a "split" map, or a "blocked" fp32 map
+        h, w = H, W
+        for li, (name, cin, cout, pool) in enumerate(VGG_LAYERS[1:]):
+            last = (name == "conv4_3")
+            oh, ow = (h // 2, w // 2) if pool else (h, w)
+            buf = ws[(li + 1) & 1][:F * oh * ow * cout]
+            use_split = (li + 1 <= n_split and mode != "blocked" and split3_supported(h, w, cin, cout, pool)
+                         and (mode == "split" or (cin <= 64 and cout == 64)))
+            if use_split:
+                nxt = VGG_LAYERS[li + 2] if not last else None
+                nh, nw_ = oh, ow
+                stay = (nxt is not None and li + 2 <= n_split and split3_supported(nh, nw_, nxt[1], nxt[2], nxt[3]))
+                key = (name, h, w)
+                if key not in self._packed_split3:
+                    self._packed_split3[key] = pack_weights_split3(self._w_hwio[name], h, w)
+                    torch.cuda.current_stream(frames.device).synchronize()    # packed once, read from every stream a pass runs on
+                dst = out if last else (buf.view(torch.float16).view(F, oh, ow, cout // 16, 2, 16) if stay else buf.view(F, oh, ow, cout))
+                x = conv3x3_relu_split3(x, self._packed_split3[key], self.packed[name][1], cin, cout, fuse_pool=pool,
+                                        out_f32=(last or not stay), out=dst)
+                mode = "split" if stay else "nhwc"
+            else:
+                if mode == "split":
+                    raise _lib.NtkError("split3 trunk: %s cannot read a split map" % name)
+                dst = out if last else buf.view(F, oh, cout // 8, ow, 8)
+                x = conv3x3_relu_wino43_blocked(x, self.packed_wino43[name], self.packed[name][1], cin, cout, fuse_pool=pool,
+                                                out_blocked=not last, out=dst)
+                mode = "blocked"
+            h, w = oh, ow
         return x
 
     def forward_chunk(self, frames, upto="conv4_3", out=None):
@@ -331,18 +454,16 @@ class VGG16Conv43(object):
                 raise _lib.NtkError("bf16 trunk runs to conv4_3 only")
             return self._forward_chunk_bf16(frames.contiguous(), out=out)
         x = frames
+        if self.split3 and upto == "conv4_3" and self.split3_trunk_supported(frames.shape):
+            if out is None:
+                out = torch.empty((frames.shape[0], frames.shape[1] // 8, frames.shape[2] // 8, 512), device=frames.device)
+            return self._forward_chunk_split3(frames.contiguous(), out)
         if (self.layout == "blocked" and self.algo == "winograd" and self.wino_waves in (None, 8) and self.features_window is None
                 and upto == "conv4_3" and blocked_trunk_supported(*frames.shape[:3])):
             # the maps between the layers live in two ping-pong workspaces per (stream, chunk shape), allocated once: a training
             # loop then makes no allocator calls in its trunk passes (the largest map, conv1_1's, is 12.8 MB per frame)
             F, H, W, _ = frames.shape
-            key = (torch.cuda.current_stream(frames.device).cuda_stream, F, H, W)
-            ws = self._blocked_ws.get(key)
-            if ws is None:
-                if len(self._blocked_ws) >= 8:                        # shapes come and go (tests, online tracking): keep the table small
-                    self._blocked_ws.clear()
-                ws = (torch.empty(F * H * W * 64, device=frames.device), torch.empty(F * (H // 2) * (W // 2) * 64, device=frames.device))
-                self._blocked_ws[key] = ws
+            ws = self._trunk_ws(frames)
             wp, b = self.packed["conv1_1"]
             x = conv3x3_relu(frames, wp, b, 3, 64, out=ws[0][:F * H * W * 64].view(F, H, W, 64))   # NHWC: conv1_2 reads it as it is
             h, w = H, W

@@ -153,6 +153,85 @@ def test_vgg_trunk_bf16_matches_bf16_oracle(cuda):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# the SPLIT form of the fp32 operator (csrc/conv_bf16p.hip, X3): every fp32 value as fp16 hi + lo, x w = xh wh + xh wl + xl wh
+# with fp32 accumulators.  Tolerance: 4e-6 of the activation scale per layer (measured 0.7e-6 .. 1.7e-6; the F(4x4) Winograd
+# kernel's bound below is 3e-5), 1e-4 through the trunk (north_star).
+@pytest.mark.parametrize("F,H,W,cin,cout,pool,in_f32,out_f32", [
+    (2, 16, 32, 64, 64, True, True, False),       # conv1_2's form: four waves, 32x8 sub-blocks, fp32 NHWC input split by the staging, pool
+    (2, 16, 32, 64, 64, False, False, False),     # ... the same shape from a split map, un-pooled
+    (3, 16, 16, 64, 64, True, True, True),        # four waves, 16x16 sub-blocks, fp32 in AND out
+    (5, 8, 8, 32, 64, False, True, False),        # four waves, 8x8 sub-blocks x 4, ragged last block, two chunks
+    (1, 32, 64, 64, 128, False, False, False),    # eight waves, 32x16 sub-blocks, 128 columns (conv2_1's form)
+    (3, 16, 16, 128, 128, True, False, False),    # 16x16 sub-blocks x 2: a block spans two frames (conv2_2's form)
+    (5, 8, 8, 128, 256, False, False, False),     # 8x8 sub-blocks x 8: ragged last block (conv3_1's form)
+    (2, 24, 8, 256, 256, True, False, True),      # 8x8 with the pool, fp32 output (conv3_3's form when the trunk leaves the split form there)
+    (3, 28, 28, 256, 512, False, False, False),   # 28-wide maps: linear tiles over 28x4 sub-blocks, 21 sub-blocks in 6 workgroups
+    (2, 28, 28, 512, 512, False, False, True),    # conv4_3's form: fp32 output
+    (1, 8, 28, 16, 64, False, False, False),      # 28 wide, one chunk, 64 columns on eight waves
+])
+def test_conv3x3_relu_split_form_matches_float64_oracle(cuda, F, H, W, cin, cout, pool, in_f32, out_f32):
+    from ntmtrack import vgg
+    assert vgg.split3_supported(H, W, cin, cout, pool)
+    rng = np.random.default_rng(23)
+    x = (np.maximum(rng.standard_normal((F, H, W, cin)), 0) * 3).astype(np.float32)       # post-ReLU-like
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    ref = O.conv3x3_same_relu(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    if pool:
+        ref = O.maxpool2x2(ref)
+    wp = vgg.pack_weights_split3(torch.from_numpy(w).to(cuda), H, W)
+    xt = torch.from_numpy(x).to(cuda)
+    out = vgg.conv3x3_relu_split3(xt if in_f32 else vgg.to_split(xt), wp, torch.from_numpy(b).to(cuda), cin, cout, fuse_pool=pool, out_f32=out_f32)
+    torch.cuda.synchronize()
+    got = (out if out_f32 else vgg.from_split(out)).cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+    assert err < 4e-6, err
+    if not out_f32:
+        # the split map a kernel writes is EXACTLY to_split() of the fp32 map the same launch writes with out_f32 (the format is pinned
+        # bit for bit: hi rounded toward zero, lo to nearest), and a second launch gives the same bits
+        y32 = vgg.conv3x3_relu_split3(xt if in_f32 else vgg.to_split(xt), wp, torch.from_numpy(b).to(cuda), cin, cout, fuse_pool=pool, out_f32=True)
+        assert torch.equal(out, vgg.to_split(y32))
+        again = vgg.conv3x3_relu_split3(xt if in_f32 else vgg.to_split(xt), wp, torch.from_numpy(b).to(cuda), cin, cout, fuse_pool=pool)
+        assert torch.equal(out, again)
+    if in_f32:                                    # the staging's split is to_split(): both routes give the same bits
+        via_map = vgg.conv3x3_relu_split3(vgg.to_split(xt), wp, torch.from_numpy(b).to(cuda), cin, cout, fuse_pool=pool, out_f32=out_f32)
+        assert torch.equal(out, via_map)
+
+
+def test_split_form_range_and_refusals(cuda):
+    """fp16's narrow exponent on both sides: weights of any magnitude (scaled by a power of two when packed: 1e-6 and 1e+6 give the
+    relative error of ordinary weights), activations beyond 65504 saturate into the low part instead of overflowing (exact up to
+    131008 at fp16 spacing), tiny activations keep fp16's absolute 6e-8; shapes the form does not take are refused, not mangled."""
+    from ntmtrack import vgg, _lib
+    rng = np.random.default_rng(29)
+    F, H, W, cin, cout = 1, 16, 16, 64, 64
+    b = np.zeros(cout, np.float32)
+    for wmag, xmag, bound in ((1e-6, 1.0, 4e-6), (1e6, 1.0, 4e-6), (1.0, 1e-2, 4e-6), (1.0, 1.0e4, 4e-6),
+                              (1.0, 2.0e4, 3e-4),               # activations up to ~9e4: those beyond 65504 carried at fp16 spacing
+                              (1.0, 1e-4, 5e-4)):               # a map that is ALL below 5e-4: the low parts are under fp16's 6e-8 floor
+        x = (np.abs(rng.standard_normal((F, H, W, cin))) * xmag).astype(np.float32)
+        w = (rng.standard_normal((3, 3, cin, cout)) * wmag / np.sqrt(9 * cin)).astype(np.float32)
+        ref = O.conv3x3_same_relu(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+        wp = vgg.pack_weights_split3(torch.from_numpy(w).to(cuda), H, W)
+        got = vgg.conv3x3_relu_split3(torch.from_numpy(x).to(cuda), wp, torch.from_numpy(b).to(cuda), cin, cout, out_f32=True).cpu().numpy()
+        err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+        assert np.isfinite(got).all() and err < bound, (wmag, xmag, err)
+    xt = torch.tensor([0.0, 1.0, -1.0, 65504.0, 70000.0, -100000.0, 131008.0, 1e9, 3e-5, -7e-8] + [0.5] * 6, device=cuda).view(1, 1, 1, 16)
+    back = vgg.from_split(vgg.to_split(xt)).view(-1)[:10].cpu().numpy()
+    assert np.allclose(back[:7], [0.0, 1.0, -1.0, 65504.0, 70000.0, -100000.0, 131008.0], rtol=2.0 ** -20, atol=0)
+    assert back[7] == 131008.0 and abs(back[8] - 3e-5) < 6e-8 and abs(back[9] + 7e-8) < 6e-8
+    assert not vgg.split3_supported(12, 12, 64, 64, False)            # neither multiples of 8 nor 28 wide
+    assert not vgg.split3_supported(28, 28, 256, 256, True)           # 28-wide maps have no pooled form
+    assert not vgg.split3_supported(16, 16, 24, 64, False) and not vgg.split3_supported(16, 16, 64, 96, False)
+    wp = vgg.pack_weights_split3(torch.zeros((3, 3, 128, 128), device=cuda), 16, 16)
+    with pytest.raises(_lib.NtkError):                                # an fp32 map is read by the four-wave form only (cin <= 64, cout = 64)
+        vgg.conv3x3_relu_split3(torch.zeros((1, 16, 16, 128), device=cuda), wp, torch.zeros(128, device=cuda), 128, 128)
+    with pytest.raises(_lib.NtkError):
+        vgg.conv3x3_relu_split3(vgg.to_split(torch.zeros((1, 16, 16, 64), device=cuda)), wp, torch.zeros(128, device=cuda), 128, 128)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # fused Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip): same operator, tolerance-level parity with the oracle
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("F,H,W,cin,cout,pool", [
@@ -316,8 +395,8 @@ def test_winograd43_window_equals_whole_frame_inside_and_touches_nothing_outside
 
 
 def test_tracker_features_roi_is_invisible_to_the_recurrent_core(cuda):
-    """features_roi=True computes conv4_3 only where extract_features reads it: the serialised NTM input, the loss and the
-    gradients are bit-identical to the whole-map tracker's."""
+    """features_roi=True computes conv4_3 only where extract_features reads it (a window of the F(4x4) Winograd kernel: the trunk then
+    runs the Winograd form): the serialised NTM input, the loss and the gradients are bit-identical to the whole-map Winograd tracker's."""
     from ntmtrack import tracker
     rng = np.random.default_rng(13)
     ws = O.init_vgg_weights(rng)
@@ -327,7 +406,7 @@ def test_tracker_features_roi_is_invisible_to_the_recurrent_core(cuda):
     offs = torch.from_numpy(rng.uniform(-0.5, 0.5, size=(B, T, 2)).astype(np.float32)).to(cuda)
     res = []
     for roi in (False, True):
-        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=cuda, seed=3, features_roi=roi)
+        trk = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=cuda, seed=3, features_roi=roi, conv_algo="winograd")
         assert trk.features_roi == roi and (trk.vgg.features_window == (4, 4, 24, 24)) == roi
         fmap = trk.vgg(frames)
         X = trk.serialize(fmap, gts0)
@@ -372,8 +451,9 @@ def test_vgg_trunk_stream_parts_do_not_change_the_result(cuda):
 
 
 def test_vgg_trunk_fullsize_matches_float64_oracle(cuda):
-    """One 224x224 frame (plus a second, so frame strides are exercised) through the DEFAULT trunk (conv1_1 direct +
-    nine fused Winograd F(4x4,3x3) layers: the 8x4x1 tile path at W = 224, 4x4x2 at 112, 2x2x8 at 56, 1x1x32 at 28),
+    """One 224x224 frame (plus a second, so frame strides are exercised) through the DEFAULT trunk (conv1_1 direct + nine layers in
+    the split form: four-wave 32x8 sub-blocks reading conv1_1's fp32 map at W = 224, 16x16 at 112, 8x8 at 56, linear 28-wide tiles at 28),
+    the F(4x4,3x3) Winograd trunk (the 8x4x1 tile path at W = 224, 4x4x2 at 112, 2x2x8 at 56, 1x1x32 at 28),
     the F(2x2,3x3) trunk and the all-direct trunk, against a float64 convolution oracle (torch-CPU conv2d in double: the second restatement of
     direct_offset_output.py:417-422 / vgg.py:155-161).  north_star tolerance: 1e-4 of the activation scale."""
     from ntmtrack import vgg
@@ -386,8 +466,11 @@ def test_vgg_trunk_fullsize_matches_float64_oracle(cuda):
     ref = OT.vgg16_conv43(frames.astype(np.float64), {k: (w.astype(np.float64), b.astype(np.float64)) for k, (w, b) in ws.items()})
     assert ref.dtype == np.float64 and ref.shape == (2, 28, 28, 512)
     x = torch.from_numpy(frames).to(cuda)
-    for algo, bound in (("winograd", 2e-5), ("winograd2", 1e-5), ("direct", 1e-5)):
-        got = vgg.VGG16Conv43(ws, device=cuda, algo=algo)(x).cpu().numpy()
+    assert vgg.VGG16Conv43(ws, device=cuda).split3                        # the default IS the split form ...
+    for algo, bound in (("split3", 1e-5), ("winograd", 2e-5), ("winograd2", 1e-5), ("direct", 1e-5)):
+        net = vgg.VGG16Conv43(ws, device=cuda, algo=algo)
+        assert algo != "split3" or (net.split3_trunk_supported(x.shape) and len(net.packed_wino43) == 9)    # ... and takes this shape
+        got = net(x).cpu().numpy()
         err = _rel(got, ref)
         print("fp32 %s trunk at 224x224 vs float64: max error / max |ref| = %.3e" % (algo, err))
         assert err < bound, (algo, err)
@@ -410,12 +493,12 @@ def test_vgg_trunk_bf16_fullsize_matches_bf16_oracle(cuda):
     assert _rel(got, ref32) < 3e-2
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_vgg_trunk_is_frame_invariant_across_chunk_boundaries(cuda, dtype):
+@pytest.mark.parametrize("dtype,algo", [("f32", "split3"), ("f32", "winograd"), ("bf16", None)])
+def test_vgg_trunk_is_frame_invariant_across_chunk_boundaries(cuda, dtype, algo):
     """BASELINE configs[3] / [4] push 1920 / 3200 frames per step through `VGG16Conv43.__call__`, i.e. through its
     `F > chunk_frames` loop (two or more chunks, each split over the stream parts).  Here: 160 frames of 224x224 with
     chunk_frames = 64 -- chunks of 64, 64 and 32 frames, the first two in two stream parts, the last in one -- against
-    ONE-FRAME launches of the same network: bit-identical, frame by frame, for the fp32 F(4x4) trunk and the bf16 trunk
+    ONE-FRAME launches of the same network: bit-identical, frame by frame, for the fp32 split-form trunk, the F(4x4) trunk and the bf16 trunk
     (a frame's result may not depend on its position in a chunk, on the chunk's size or on the stream it ran on)."""
     from ntmtrack import vgg
     rng = np.random.default_rng(21)
@@ -427,16 +510,16 @@ def test_vgg_trunk_is_frame_invariant_across_chunk_boundaries(cuda, dtype):
     # 160 different frames from 8 random ones: frame f = base[f % 8] rolled by f // 8 pixels (cheap on the host, no two alike)
     frames = torch.from_numpy(base).to(cuda)
     frames = torch.stack([torch.roll(frames[f % 8], shifts=f // 8, dims=1) for f in range(F)]).contiguous()
-    net = vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, chunk_frames=64)
+    net = vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, chunk_frames=64, algo=algo)
     got = net(frames)
     torch.cuda.synchronize()
     assert got.shape == (F, 28, 28, 512) and got.dtype == torch.float32
-    one = vgg.VGG16Conv43(ws, device=cuda, dtype=dtype)
+    one = vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, algo=algo)
     for f in range(F):
         ref = one(frames[f:f + 1])
         assert torch.equal(got[f:f + 1], ref), "frame %d (chunk %d, position %d) differs from its one-frame launch" % (f, f // 64, f % 64)
     # and the whole batch in one chunk (what the 640-frame bench pass does)
-    assert torch.equal(vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, chunk_frames=1024)(frames), got)
+    assert torch.equal(vgg.VGG16Conv43(ws, device=cuda, dtype=dtype, chunk_frames=1024, algo=algo)(frames), got)
 
 
 def test_blocked_trunk_layers_equal_nhwc_layers_bit_for_bit(cuda):
