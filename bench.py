@@ -28,14 +28,19 @@ import torch
 # counts 128-B requests at 64 B) + --pmc WRITE_SIZE, separate passes -- profiles/r01_vgg_trunk_hbm_traffic_pmc.csv
 # (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
-TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": 9.0467e10 + 2.3860e10}
+TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": 9.0467e10 + 2.3860e10,
+                                  "split3": None}
 TRUNK_TRAFFIC_PROFILE = {"direct": "profiles/r01_vgg_trunk_hbm_traffic_pmc.csv", "winograd2": "profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv",
-                         "winograd": "profiles/r04_vgg_trunk_blocked_hbm_traffic_pmc.csv"}
+                         "winograd": "profiles/r04_vgg_trunk_blocked_hbm_traffic_pmc.csv", "split3": None}
 # fraction of the direct-convolution multiplies the Winograd layers execute on the MFMA pipe: F(2x2,3x3) 16 per 2x2 tile
 # where the direct form has 36; F(4x4,3x3) 36 per 4x4 tile where it has 144
 WINO_EXECUTED_FRACTION = {"winograd": 36.0 / 144.0, "winograd2": 16.0 / 36.0}
 NTM_FWD_TRAFFIC_BYTES_B32_S1300 = 1.448e8 + 1.036e9     # profiles/r04_ntm_seq_hbm_traffic_pmc.csv (FETCH_SIZE KB x 1024 x 2 + WRITE_SIZE KB x 1024)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 peak (v_mfma_f32_32x32x16_f16: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+# The split form (csrc/conv_bf16p.hip X3) executes THREE fp16 MFMA products per fp32 product of conv1_2 .. conv4_3 (conv1_1 stays on
+# the fp32 pipe: 0.6 % of the flops)
+SPLIT3_PRODUCTS = 3.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -337,7 +342,7 @@ def main():
     ap.add_argument("--model", default="ntm", choices=["ntm", "dnc"],
                     help="ntm = BASELINE configs[1] (the headline metric); dnc = configs[2] (DNC 256x64, 4 read heads), reported for reference")
     ap.add_argument("--wino-waves", type=int, default=0, choices=[0, 4, 8], help="form of the F(4x4) kernel (0 = library default = 8)")
-    ap.add_argument("--conv-algo", default="winograd", choices=["winograd", "winograd2", "direct"],
+    ap.add_argument("--conv-algo", default="split3", choices=["split3", "winograd", "winograd2", "direct"],
                     help="fp32 trunk: fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (default) or the direct implicit-GEMM kernel")
     ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact fp32 MFMA (configs 2-4, the headline); bf16 = bf16 operands / fp32 accumulate (config 5)")
@@ -479,8 +484,11 @@ def main():
         if args.features_roi and getattr(trk, "features_roi", False):      # conv4_3 in 25 of its 49 tiles only
             flops -= 2 * 28 * 28 * 9 * 512 * 512 * B * T * (24.0 / 49.0)
         executed_flops = (c11 + (flops - c11) * WINO_EXECUTED_FRACTION[args.conv_algo]) if wino else flops
+        split3 = args.conv_dtype == "f32" and bool(getattr(trk.vgg, "split3", False)) and trk.vgg.split3_trunk_supported(frames.shape)
+        if split3:
+            executed_flops = (flops - c11) * SPLIT3_PRODUCTS                # on the fp16 pipe (conv1_1's fp32 MFMAs are not counted)
         achieved = executed_flops / (vgg_ms * 1e-3) / 1e12
-        PEAK = FP32_MFMA_PEAK_TFLOPS if args.conv_dtype == "f32" else 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+        PEAK = (F16_MFMA_PEAK_TFLOPS if split3 else FP32_MFMA_PEAK_TFLOPS) if args.conv_dtype == "f32" else 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
         out = {
             "metric": ("frames/sec (whole node) VGG16+NTM(128x20) seq_len=%d" % T) if args.model == "ntm" else
                       ("frames/sec (whole node) VGG16+DNC(%dx%d) seq_len=%d" % (trk.core.N, trk.core.W, T)),
@@ -488,7 +496,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_dtype == "f32" else "bf16 conv operands / f32 accumulate, f32 memory cell",
+            "dtype": ("f32 (conv1_2..conv4_3: each fp32 value as fp16 hi + lo, each product as three fp16 MFMA products, f32 accumulate: "
+                      "2^-20 per product, measured error at or below the fp32 Winograd trunk's; memory cell f32)" if split3 else "f32")
+                     if args.conv_dtype == "f32" else "bf16 conv operands / f32 accumulate, f32 memory cell",
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: VGG-16 conv1_1..conv4_3 + NTMCell(128x20, hidden 200, R4/W1) "
                                     "direct_offset_output %s step, batch %d sequences/GPU, seq_len %d, 224x224 frames"
@@ -501,19 +511,21 @@ def main():
                        **({"features_roi": "conv4_3 computed in the 25 of 49 output tiles extract_features reads (optional; the flops "
                                            "in `roofline` are reduced accordingly; NOT the headline configuration)"}
                           if (args.features_roi and getattr(trk, "features_roi", False)) else {})},
-            "roofline": {"bound": "mfma", "kernel": ((("conv3x3_wino43d_kernel" if trk.vgg.wino_waves in (None, 8) else "conv3x3_wino43_kernel (four-wave form)")
+            "roofline": {"bound": "mfma", "kernel": ("conv3x3_relu_bf16p_kernel<X3> (VGG trunk: conv1_1 on the fp32 pipe + conv1_2 .. conv4_3 in the split form)" if split3 else
+                                                     ((("conv3x3_wino43d_kernel" if trk.vgg.wino_waves in (None, 8) else "conv3x3_wino43_kernel (four-wave form)")
                                                       + " (VGG trunk: conv1_1 direct + 9 fused Winograd F(4x4,3x3) layers; a 1x1x32-block layer"
                                                         " whose blocks span more than 16 MB of input falls back to the four-wave form)"
                                                       if args.conv_algo == "winograd" else
                                                       ("conv3x3_wino_kernel (VGG trunk: conv1_1 direct + 9 fused Winograd F(2x2,3x3) layers)"
                                                        if args.conv_algo == "winograd2" else "conv3x3_relu_dma_kernel (VGG trunk, 10 layers)"))
-                                                     if args.conv_dtype == "f32" else "conv3x3_relu_bf16_kernel (VGG trunk, 10 layers)"),
+                                                     if args.conv_dtype == "f32" else "conv3x3_relu_bf16_kernel (VGG trunk, 10 layers)")),
                          "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4),
                          "frac_algorithmic": round(algorithmic / PEAK, 4),
+                         "algorithmic_over_fp32_mfma_peak": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo] * (B * T) / 640.0)
-                         if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo]) else None,
-                         "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (%s), scaled by frames/640; algorithmic 4.563e10 B per 640 frames" % TRUNK_TRAFFIC_PROFILE[args.conv_algo],
+                         if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES.get(args.conv_algo)) else None,
+                         "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (%s), scaled by frames/640; algorithmic 4.563e10 B per 640 frames" % TRUNK_TRAFFIC_PROFILE.get(args.conv_algo),
                          "algorithmic_flops_per_frame": conv_flops_per_frame(),
                          "executed_flops_per_frame": executed_flops / (B * T),
                          "algorithmic_tflops": round(algorithmic, 2),
@@ -525,7 +537,14 @@ def main():
                                   "; the trunk pass runs as %d stream part(s): with 2, kernel durations in a rocprof --stats summary overlap "
                                   "pairwise (scripts/trace_union.py gives the union of their intervals per pass)")
                                  % (WINO_EXECUTED_FRACTION[args.conv_algo], getattr(trk.vgg, "split_streams", 1))
-                                 if wino else "direct convolution: executed = algorithmic flops"},
+                                 if wino else
+                                 ("achieved / frac = EXECUTED fp16 MFMA flops (3 x the direct-convolution count of conv1_2 .. conv4_3) / trunk time "
+                                  "measured with HIP events on the trunk's stream inside the timed region, against the dense fp16 peak at 2.4 GHz "
+                                  "(the chip holds 1.5 - 1.75 GHz in these kernels and their MFMA pipe is busy 63 - 84 %% of the cycles: "
+                                  "profiles/r04_split3_pmc.txt); algorithmic_tflops = the direct-convolution count (SURVEY 8d: 27.92 GFLOP/frame) / the "
+                                  "same time, algorithmic_over_fp32_mfma_peak = that against the fp32 pipe's 157.3 TFLOP/s (the peak rounds 1 - 3 priced "
+                                  "the trunk against); the trunk pass runs as %d stream part(s)" % getattr(trk.vgg, "split_streams", 1))
+                                 if split3 else "direct convolution: executed = algorithmic flops"},
             "breakdown_ms": {"vgg_trunk_stream": round(vgg_ms, 3), "ntm_fwd_bwd_opt_stream": round(ntm_ms, 3),
                              "steady_state_step": steady_ms,
                              "note": "two HIP streams: VGG(i+1) overlaps NTM(i); per-stream event times; steady_state_step = median interval "
