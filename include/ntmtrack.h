@@ -87,7 +87,7 @@ int ntk_vgg_conv3x3_relu_f32_to_bf16(const float* in, const float* w_packed, con
  * bf16 matrix pipe.  Every fp32 value v travels as hi = bf16(v), lo = bf16(v - hi); a product x w is accumulated in fp32 as
  * xh wh + xh wl + xl wh (relative error of the split 2^-17: per layer 4e-6 .. 5e-6 of the activation scale, what the F(4x4) Winograd
  * kernel has).  A split map is [frames][H][W][C / 16][2][16] bf16 (hi x16 | lo x16 per group of 16 channels: the bytes of the fp32 map).
- * Shapes: H, W multiples of 8, or W = 28 with H a multiple of 4 and no pool; cin a multiple of 16, cout of 64.  Packed weights:
+ * Shapes: H, W multiples of 8, or W = 28 with H >= 20 (not a multiple of 8) and no pool; cin a multiple of 16, cout of 64.  Packed weights:
  * 18 * cin * cout bf16 elements, packed per layer and frame shape.  out_f32 = 1 writes fp32 NHWC (where the trunk leaves the split
  * form); in_f32 = 1 reads an fp32 NHWC map and splits it while staging (where the trunk enters it: cin <= 64 and cout = 64 only). */
 size_t ntk_vgg_split3_packed_elems(int cin, int cout);

@@ -173,8 +173,11 @@ __global__ void split3_pack_kernel(const float* __restrict__ w, _Float16* __rest
 // narrow exponent is handled on both sides: weights are scaled by a power of two when packed, activations saturate instead of
 // overflowing.)  A "step" becomes a tap: 24 MFMAs per wave on four fragment
 // sets (xh, xl, wh, wl), the three products of a tap software-pipelined against each other's fragment reads.
-// LIN: sub-blocks of TW x TH pixels whose width is not a power of two (28 x 4: the 28 x 28 maps of conv4_x); tiles are then cut from
-// the workgroup's pixels in linear order (a tile may span two sub-blocks) and the last PNT * 32 - NSUB * TW * TH pixels are padding.
+// ROWS (TW not a power of two: the 28 x 28 maps of conv4_x, TW = W = 28): no sub-blocks -- a workgroup takes 512 CONSECUTIVE pixels
+// of the batch in (frame, row, column) order, about 18.3 image rows, whatever frame they belong to (no padding tiles; first version:
+// 28 x 4 sub-blocks, four per workgroup = 448 of 512 columns used).  Its patch is the run's rows plus one above and one below, with ONE
+// all-zero row between two frames (the row below a frame's last row and above the next frame's first): image row (f, y) sits in patch
+// row (f - f0)(H + 1) + y + 1 - y0, so a tap is the same uniform shift as everywhere else.  H >= 20: at most one frame boundary per run.
 // INF32 (split form, four-wave workgroups): the input is an fp32 NHWC map and the STAGING splits it -- 16-byte pieces through registers
 // (two or three per lane and stage, requested at the top of a stage, split and written to the patch image at its end) instead of DMA.
 // That is how the trunk enters the split form: conv1_1 keeps its fp32 kernel and conv1_2 reads its map as it is.
@@ -182,9 +185,9 @@ template <int BN, int TW, int TH, int NSUB, int KC, bool POOL, bool OUTF32, int 
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_relu_bf16p_kernel(Bf16pArgs a) {
     static_assert(!INF32 || (X3 && NW == 4), "fp32 input: split form on four waves (the eight-wave form has no registers for the staging)");
     constexpr int PNT = 2 * NW;                                                 // 32-pixel tiles per workgroup
-    constexpr bool LIN = (TW & (TW - 1)) != 0;
+    constexpr bool ROWS = (TW & (TW - 1)) != 0;
     static_assert(!X3 || KC == 32, "split form: 16 real channels = one 32-channel chunk");
-    static_assert(!LIN || !POOL, "linear tiles have no row pairs");
+    static_assert(!ROWS || (!POOL && NSUB == 1 && (TW - 1 + 32 * PNT - 1) / TW + 1 <= TH - 1 && NW == 8), "runs of rows: no row pairs; TH = the patch's image rows");
     static_assert(NW == 8 || (NW == 4 && BN == 64), "four-wave workgroups take 64 columns");
     constexpr int PW = TW + 2, PH = TH + 2, SPX = PW * PH, NPX = NSUB * SPX;
     constexpr int PIXB = KC * 2, PIECES = KC / 8, PPP = 1024 / PIXB;            // bytes per pixel row, 16-B pieces per row, rows per DMA
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int TM = BN == 128 ? 4 : 2;                                       // pixel tiles per wave (two column tiles either way)
     constexpr int TPS = (TW * TH) / 32;                                         // tiles per sub-block (0: two sub-blocks per tile)
     constexpr int K16 = KC / 16;
-    static_assert(LIN ? NSUB * TW * TH <= 32 * PNT : NSUB * TW * TH == 32 * PNT, "512 (256) output pixels per workgroup");
+    static_assert(ROWS || NSUB * TW * TH == 32 * PNT, "512 (256) output pixels per workgroup");
     constexpr int TRB = POOL ? 0 : NW * TM * 32 * 144;                           // the un-pooled epilogue's transpose image (below)
     constexpr int LDSB = (2 * ABYTES + 2 * SBYTES) > TRB ? (2 * ABYTES + 2 * SBYTES) : TRB;
     static_assert(LDSB + 1024 <= (NW == 8 ? 160 : 80) * 1024, "LDS");
@@ -221,7 +224,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     if (sp >= a.NS) return;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-    if (tid < NSUB) {
+    // ROWS: first pixel of the run, its global row g0 = (frame rf0, row ry0)
+    const int rP0 = sp * (32 * PNT), rg0 = ROWS ? rP0 / TW : 0, rf0 = ROWS ? rg0 / H : 0, ry0 = ROWS ? rg0 - rf0 * H : 0;
+    if (!ROWS && tid < NSUB) {
         const int sq = sp * NSUB + tid;
         if (sq < a.NQ) {
             const int bx = sq % a.bxN;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __syncthreads();
 
     // ---- patch DMA: this wave's pieces pa = wave + 8 i; a lane = one 16-byte slot of one LDS pixel row
-    const int f0 = ((sp * NSUB) / a.bxN) / a.byN;
+    const int f0 = ROWS ? rf0 : ((sp * NSUB) / a.bxN) / a.byN;
     const size_t in_left = (size_t)(a.frames - f0) * H * W * Cin * sizeof(__bf16);
     const unsigned in_bytes = (unsigned)(in_left < 0x7ffffff0ull ? in_left : 0x7ffffff0ull);
     const __bf16* pin = a.in + (size_t)f0 * H * W * Cin;
@@ -247,8 +252,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (pa < NPA && lp < NPX) {
             const int q = lp / SPX, rem = lp - q * SPX;
             const int py = rem / PW, px = rem - py * PW;
-            const int fq = s_sbf[q];
-            const int y = s_sby[q] - 1 + py, x = s_sbx[q] - 1 + px;
+            int fq, y;
+            const int x = (ROWS ? 0 : s_sbx[q]) - 1 + px;
+            if constexpr (ROWS) {                                               // patch row py <-> virtual row U = ry0 + py, H + 1 per frame
+                const int U = ry0 + py, df = U / (H + 1);
+                fq = rf0 + df; y = U - df * (H + 1) - 1;                        // y = -1: the zero row above a frame
+                if (fq >= a.frames) fq = -1;
+            } else {
+                fq = s_sbf[q]; y = s_sby[q] - 1 + py;
+            }
             if (fq >= 0 && y >= 0 && y < H && x >= 0 && x < W)
                 aoff[i] = (unsigned)(((((size_t)(fq - f0) * H + y) * W + x) * Cin + (slot ^ p_sw<PIECES>(lp)) * 8) * sizeof(__bf16));
         }
@@ -319,36 +331,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // patch pixel (tap 0,0 = the output pixel itself, halo offset included) of this lane's column in each of its tiles
     int pix0[TM];
     int opix[TM];                                                               // output pixel (element offset / Cout) or -1
-    // column m of tile t -> sub-block q and pixel (y, x) inside it; false: a padding column (LIN only)
-    auto tile_pixel = [&](int t, int m, int& q, int& y, int& x) -> bool {
-        if constexpr (LIN) {
-            const int lin = t * 32 + m;
-            if (lin >= NSUB * TW * TH) { q = 0; y = 0; x = 0; return false; }
-            q = lin / (TW * TH);
-            const int rem = lin - q * (TW * TH);
-            y = rem / TW; x = rem - y * TW;
-        } else if constexpr (TPS == 0) {                                        // 4x4 sub-blocks: two per tile
-            q = 2 * t + (m >> 4); y = (m >> 2) & 3; x = m & 3;
+    // column m of tile t -> its patch pixel pc (the tap (0, 0) operand, halo offset included) and its output pixel op (pooled: of
+    // the 2x2 window's result), -1 where the column is beyond the batch
+    auto locate = [&](int t, int m, int& pc, int& op) {
+        if constexpr (ROWS) {
+            const int P = rP0 + t * 32 + m;
+            const int g = P / TW, x = P - g * TW, f = g / H, y = g - f * H;
+            const bool real = f < a.frames;
+            pc = real ? ((f - rf0) * (H + 1) + y + 1 - ry0) * PW + x + 1 : PW + 1;
+            op = real ? P : -1;
         } else {
-            constexpr int RPT = 32 / TW;                                        // rows of a sub-block per tile
-            const int tl = t % TPS, j = m / TW;
-            q = t / TPS;
-            y = 2 * ((tl >> 1) * RPT + j) + (tl & 1);                           // rows y, y + 1 sit in consecutive tiles (the pool's pairs)
-            x = m % TW;
+            int q, y, x;
+            if constexpr (TPS == 0) {                                           // 4x4 sub-blocks: two per tile
+                q = 2 * t + (m >> 4); y = (m >> 2) & 3; x = m & 3;
+            } else {
+                constexpr int RPT = 32 / TW;                                    // rows of a sub-block per tile
+                const int tl = t % TPS, j = m / TW;
+                q = t / TPS;
+                y = 2 * ((tl >> 1) * RPT + j) + (tl & 1);                       // rows y, y + 1 sit in consecutive tiles (the pool's pairs)
+                x = m % TW;
+            }
+            pc = q * SPX + (y + 1) * PW + (x + 1);
+            const int fq = s_sbf[q];
+            const int Y = s_sby[q] + y, X = s_sbx[q] + x;
+            if constexpr (POOL) op = fq < 0 ? -1 : ((fq * (H >> 1) + (Y >> 1)) * (W >> 1) + (X >> 1));
+            else op = fq < 0 ? -1 : ((fq * H + Y) * W + X);
         }
-        return true;
     };
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int t = wm * TM + tm;
-        int q, y, x;
-        const bool real = tile_pixel(t, mcol, q, y, x);
-        pix0[tm] = q * SPX + (y + 1) * PW + (x + 1);
-        const int fq = real ? s_sbf[q] : -1;
-        const int Y = s_sby[q] + y, X = s_sbx[q] + x;
-        if constexpr (POOL) opix[tm] = fq < 0 ? -1 : ((fq * (H >> 1) + (Y >> 1)) * (W >> 1) + (X >> 1));
-        else opix[tm] = fq < 0 ? -1 : ((fq * H + Y) * W + X);
-    }
+    for (int tm = 0; tm < TM; ++tm) locate(wm * TM + tm, mcol, pix0[tm], opix[tm]);
     // LDS byte offsets (inside patch buffer 0) of this lane's A-operand fragments, per tap and tile, for the first 16-channel half of a
     // chunk (the second half is the same address with bit 5 flipped: the other slot pair of the pixel's 64-byte row).  They are the same
     // in every chunk, so they are computed ONCE and toggled between the two patch buffers per chunk: recomputed per step (pixel shift,
@@ -624,12 +635,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int j = 0; j < TM * 4; ++j) {
                 const int tmr = j >> 2, mr = 8 * (j & 3) + (lane >> 3), piece = lane & 7;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tr + (tmr * 32 + mr) * RB + piece * 16);
-                const int t = wm * TM + tmr;
-                int q, y, x;
-                const bool real = tile_pixel(t, mr, q, y, x);
-                const int fq = real ? s_sbf[q] : -1;
-                if (fq >= 0) {
-                    const size_t op = ((size_t)(fq * H + s_sby[q] + y) * W + s_sbx[q] + x) * Cout + cb * BN + wn * 64;
+                int pc_, opx;
+                locate(wm * TM + tmr, mr, pc_, opx);
+                if (opx >= 0) {
+                    const size_t op = (size_t)opx * Cout + cb * BN + wn * 64;
                     if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + op + ps * 32 + piece * 4) = v;
                     else if constexpr (X3) *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.out) + 2 * (op + ps * 32) + piece * 8) = v;
                     else *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.out) + op + piece * 8) = v;
@@ -643,18 +652,18 @@ template <int BN, int KC, int NW, bool X3 = false, bool INF32 = false>
 int bf16p_launch(const Bf16pArgs& a0, int H, int W, int pool, int out_f32, hipStream_t st) {
     Bf16pArgs a = a0;
     if constexpr (X3 && !INF32) {
-        if (W == 28 && H % 4 == 0 && !(H % 8 == 0 && W % 8 == 0)) {            // 28 x 4 sub-blocks, four per workgroup, linear tiles
-            if (pool || NW != 8) return NTK_ERR_UNSUPPORTED;
-            a.bxN = 1; a.byN = H / 4;
-            const long long NQ = (long long)a.frames * a.byN, NS = (NQ + 3) / 4;
-            a.NQ = (int)NQ; a.NS = (int)NS; a.nCB = a.Cout / BN;
+        if (W == 28 && !(H % 8 == 0)) {                                         // runs of 512 consecutive pixels over 28-wide rows
+            if (pool || NW != 8 || H < 20) return NTK_ERR_UNSUPPORTED;
+            a.bxN = 1; a.byN = 1;
+            const long long NQ = (long long)a.frames * H * W, NS = (NQ + 511) / 512;
+            a.NQ = 0; a.NS = (int)NS; a.nCB = a.Cout / BN;
             long long slots;
             if (a.nCB >= 8) slots = NS * (a.nCB / 8);
             else { const int per = 8 / a.nCB; slots = (NS + per - 1) / per; }
             const unsigned grid = (unsigned)(slots * 8);
             if constexpr (NW == 8) {
-                if (out_f32) conv3x3_relu_bf16p_kernel<BN, 28, 4, 4, 32, false, true, 8, true><<<grid, 512, 0, st>>>(a);
-                else conv3x3_relu_bf16p_kernel<BN, 28, 4, 4, 32, false, false, 8, true><<<grid, 512, 0, st>>>(a);
+                if (out_f32) conv3x3_relu_bf16p_kernel<BN, 28, 21, 1, 32, false, true, 8, true><<<grid, 512, 0, st>>>(a);
+                else conv3x3_relu_bf16p_kernel<BN, 28, 21, 1, 32, false, false, 8, true><<<grid, 512, 0, st>>>(a);
             }
             return NTK_OK;
         }
@@ -779,9 +788,9 @@ extern "C" int ntk_vgg_conv3x3_relu_bf16p(const void* in_bf16, const void* w_pac
 // The SPLIT form (X3): the fp32 trunk on the bf16 matrix pipe.  Maps are "split" maps: [frames][H][W][C / 16][hi x16 | lo x16] bf16.
 // ---------------------------------------------------------------------------------------------------------------------------------
 static int split3_form(int H, int W, int cin, int cout, int pool, int* bn, int* nw) {
-    if ((H % 4) || (W % 4) || cin % 16 || cout % 64) return 0;
+    if (H <= 0 || W <= 0 || cin % 16 || cout % 64) return 0;
     const bool rect = (W % 8 == 0 && H % 8 == 0);
-    if (!rect && (pool || W != 28)) return 0;
+    if (!rect && (pool || W != 28 || H < 20)) return 0;                          // 28-wide maps: runs of rows (conv4_x), un-pooled
     *nw = (rect && cin <= 64 && cout == 64) ? 4 : 8;
     *bn = (*nw == 8 && cout % 128 == 0) ? 128 : 64;
     const int nCB = cout / *bn;
@@ -823,8 +832,8 @@ extern "C" int ntk_vgg_conv3x3_relu_split3(const void* in_split, const void* w_p
                 "ntk_vgg_conv3x3_relu_split3: pointers must be 16-byte aligned");
     int bn = 0, nw = 0;
     NTK_REQUIRE(frames > 0 && H > 0 && W > 0 && split3_form(H, W, cin, cout, fuse_pool, &bn, &nw), NTK_ERR_UNSUPPORTED,
-                "ntk_vgg_conv3x3_relu_split3: frames=%d H=%d W=%d cin=%d cout=%d pool=%d (H, W multiples of 8, or W = 28 and H a multiple "
-                "of 4 without the pool; cin a multiple of 16, cout of 64)", frames, H, W, cin, cout, fuse_pool);
+                "ntk_vgg_conv3x3_relu_split3: frames=%d H=%d W=%d cin=%d cout=%d pool=%d (H, W multiples of 8, or W = 28 and H >= 20 "
+                "without the pool; cin a multiple of 16, cout of 64)", frames, H, W, cin, cout, fuse_pool);
     NTK_REQUIRE((unsigned long long)2 * H * W * cin * 4 <= 0x7ffffff0ull && (long long)frames * H * W < (1ll << 31), NTK_ERR_UNSUPPORTED,
                 "ntk_vgg_conv3x3_relu_split3: frame too large for 32-bit offsets");
     Bf16pArgs a;

@@ -165,9 +165,9 @@ def test_vgg_trunk_bf16_matches_bf16_oracle(cuda):
     (3, 16, 16, 128, 128, True, False, False),    # 16x16 sub-blocks x 2: a block spans two frames (conv2_2's form)
     (5, 8, 8, 128, 256, False, False, False),     # 8x8 sub-blocks x 8: ragged last block (conv3_1's form)
     (2, 24, 8, 256, 256, True, False, True),      # 8x8 with the pool, fp32 output (conv3_3's form when the trunk leaves the split form there)
-    (3, 28, 28, 256, 512, False, False, False),   # 28-wide maps: linear tiles over 28x4 sub-blocks, 21 sub-blocks in 6 workgroups
+    (3, 28, 28, 256, 512, False, False, False),   # 28-wide maps: runs of 512 consecutive pixels (18.3 rows), five workgroups, two of them across a frame boundary
     (2, 28, 28, 512, 512, False, False, True),    # conv4_3's form: fp32 output
-    (1, 8, 28, 16, 64, False, False, False),      # 28 wide, one chunk, 64 columns on eight waves
+    (5, 20, 28, 16, 64, False, False, False),     # 28 wide, 20 rows (the shortest frame the form takes), one chunk, 64 columns on eight waves
 ])
 def test_conv3x3_relu_split_form_matches_float64_oracle(cuda, F, H, W, cin, cout, pool, in_f32, out_f32):
     from ntmtrack import vgg
@@ -222,6 +222,7 @@ def test_split_form_range_and_refusals(cuda):
     assert np.allclose(back[:7], [0.0, 1.0, -1.0, 65504.0, 70000.0, -100000.0, 131008.0], rtol=2.0 ** -20, atol=0)
     assert back[7] == 131008.0 and abs(back[8] - 3e-5) < 6e-8 and abs(back[9] + 7e-8) < 6e-8
     assert not vgg.split3_supported(12, 12, 64, 64, False)            # neither multiples of 8 nor 28 wide
+    assert not vgg.split3_supported(12, 28, 64, 64, False)            # 28 wide but fewer than 20 rows (a run could cross two frame boundaries)
     assert not vgg.split3_supported(28, 28, 256, 256, True)           # 28-wide maps have no pooled form
     assert not vgg.split3_supported(16, 16, 24, 64, False) and not vgg.split3_supported(16, 16, 64, 96, False)
     wp = vgg.pack_weights_split3(torch.zeros((3, 3, 128, 128), device=cuda), 16, 16)
