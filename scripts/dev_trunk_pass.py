@@ -7,7 +7,7 @@ import torch
 from ntmtrack import vgg
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 640
-algo = sys.argv[2] if len(sys.argv) > 2 else "winograd"      # winograd | winograd2 | direct | bf16 (config 5's bf16 MFMA trunk)
+algo = sys.argv[2] if len(sys.argv) > 2 else "split3"        # split3 | winograd | winograd2 | direct | bf16 (config 5's bf16 MFMA trunk)
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(42)
 ws = {}
