@@ -29,9 +29,10 @@ import torch
 # (direct kernels) and profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv (default trunk).
 # Algorithmic bytes (inputs + weights + outputs of the ten layers) are 4.563e10.
 TRUNK_TRAFFIC_BYTES_640_FRAMES = {"direct": 5.4737e10 + 2.3121e10, "winograd2": 8.3752e10 + 2.3121e10, "winograd": 9.0467e10 + 2.3860e10,
-                                  "split3": None}
+                                  "split3": 5.4769e10 + 2.3734e10}
 TRUNK_TRAFFIC_PROFILE = {"direct": "profiles/r01_vgg_trunk_hbm_traffic_pmc.csv", "winograd2": "profiles/r01_vgg_trunk_winograd_hbm_traffic_pmc.csv",
-                         "winograd": "profiles/r04_vgg_trunk_blocked_hbm_traffic_pmc.csv", "split3": None}
+                         "winograd": "profiles/r04_vgg_trunk_blocked_hbm_traffic_pmc.csv",
+                         "split3": "profiles/r04_vgg_trunk_split3_hbm_traffic_pmc.csv"}
 # fraction of the direct-convolution multiplies the Winograd layers execute on the MFMA pipe: F(2x2,3x3) 16 per 2x2 tile
 # where the direct form has 36; F(4x4,3x3) 36 per 4x4 tile where it has 144
 WINO_EXECUTED_FRACTION = {"winograd": 36.0 / 144.0, "winograd2": 16.0 / 36.0}
@@ -342,8 +343,10 @@ def main():
     ap.add_argument("--model", default="ntm", choices=["ntm", "dnc"],
                     help="ntm = BASELINE configs[1] (the headline metric); dnc = configs[2] (DNC 256x64, 4 read heads), reported for reference")
     ap.add_argument("--wino-waves", type=int, default=0, choices=[0, 4, 8], help="form of the F(4x4) kernel (0 = library default = 8)")
-    ap.add_argument("--conv-algo", default="split3", choices=["split3", "winograd", "winograd2", "direct"],
-                    help="fp32 trunk: fused Winograd F(2x2,3x3) on the fp32 MFMA pipe (default) or the direct implicit-GEMM kernel")
+    ap.add_argument("--conv-algo", default=None, choices=["split3", "winograd", "winograd2", "direct"],
+                    help="fp32 trunk form (default: the tracker's own -- the split form for the NTM tracker, F(4x4) Winograd for the DNC "
+                         "tracker): split3 = three fp16 MFMA products per fp32 product, winograd / winograd2 = fused F(4x4) / F(2x2) on the "
+                         "fp32 MFMA pipe, direct = the implicit-GEMM kernel")
     ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact fp32 MFMA (configs 2-4, the headline); bf16 = bf16 operands / fp32 accumulate (config 5)")
     ap.add_argument("--mem-size", type=int, default=None)
@@ -389,6 +392,8 @@ def main():
                                        features_roi=args.features_roi)   # same init on every rank
     if args.wino_waves:
         trk.vgg.wino_waves = args.wino_waves
+    if args.conv_algo is None:                                      # what the tracker chose (reported below)
+        args.conv_algo = "split3" if getattr(trk.vgg, "split3", False) else trk.vgg.algo
     log("tracker built; generating synthetic inputs")
     from ntmtrack import parallel
     lo, hi = parallel.shard_range(world * B, rank, world)          # this rank's sequences of the global batch

@@ -329,6 +329,11 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
+        if conv_algo is None:
+            # The DNC steps are bound by their cluster kernels, which share the chip (and its clock) with the trunk: beside the split-form
+            # trunk (the fp16 matrix pipe at 1.6 - 1.75 GHz) they run 2 % slower than beside the Winograd trunk, and the trunk's own time
+            # is hidden either way (configs[2]: 6 020 against 6 145 frames/s, same box) -> the Winograd form unless asked otherwise
+            conv_algo = os.environ.get("NTK_TRUNK_ALGO", "winograd")
         self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
         self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and self.vgg.algo == "winograd"
         if self.features_roi:          # conv4_3 only where extract_features reads it (GRID_START .. GRID_START + (GRID_N - 1) * GRID_STEP), whole 4x4 tiles
