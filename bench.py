@@ -501,9 +501,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (conv1_2..conv4_3: each fp32 value as fp16 hi + lo, each product as three fp16 MFMA products, f32 accumulate: "
-                      "2^-20 per product, measured error at or below the fp32 Winograd trunk's; memory cell f32)" if split3 else "f32")
-                     if args.conv_dtype == "f32" else "bf16 conv operands / f32 accumulate, f32 memory cell",
+            "dtype": "f32" if args.conv_dtype == "f32" else "bf16 conv operands / f32 accumulate, f32 memory cell",
+            **({"dtype_note": "fp32 values and fp32 accumulators everywhere; in conv1_2 .. conv4_3 each fp32 operand is carried as two fp16 numbers "
+                              "(hi + lo = the value to 2^-22) and each product is three fp16 MFMA products (2^-20 per product): measured against "
+                              "float64, 0.7e-6 - 1.7e-6 of the activation scale per layer and 3.0e-6 through the trunk (the fp32 F(4x4) Winograd "
+                              "trunk: 6e-6 - 1.5e-5 and 3.5e-6; north_star allows 1e-4); DESIGN.md 4.0''"} if split3 else {}),
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: VGG-16 conv1_1..conv4_3 + NTMCell(128x20, hidden 200, R4/W1) "
                                     "direct_offset_output %s step, batch %d sequences/GPU, seq_len %d, 224x224 frames"
