@@ -1,12 +1,15 @@
 #!/bin/bash
 # GPU box: MFMA-pipe busy share and effective clock of the split-form layers (one --pmc pass, kernel trace only)
-OUT=gpurun_out/r04_s3
+# usage: split3_pmc.sh [bf16]      (bf16: the same for config 5's bf16 patch-form layers, scripts/r04/bf16_trunk.py)
+OUT=gpurun_out/r04_s3${1:+_$1}
+if [ "$1" = bf16 ]; then TARGET="scripts/r04/bf16_trunk.py 640"; else TARGET="scripts/r04/split3_layers.py 640 only3"; fi
+export PMC_ROOT=$OUT/pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- python3 scripts/r04/split3_layers.py 640 only3 > $OUT/pmc.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- python3 $TARGET > $OUT/pmc.log 2>&1 || exit 1
 python3 - <<'PY'
-import csv, glob, collections
-root = "gpurun_out/r04_s3/pmc"
+import csv, glob, collections, os
+root = os.environ["PMC_ROOT"]
 cc = max(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
 kt = max(glob.glob(root + "/**/*kernel_trace.csv", recursive=True))
 dur = {int(r["Dispatch_Id"]): (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt))}
