@@ -392,8 +392,10 @@ def main():
                                        features_roi=args.features_roi)   # same init on every rank
     if args.wino_waves:
         trk.vgg.wino_waves = args.wino_waves
-    if args.conv_algo is None:                                      # what the tracker chose (reported below)
-        args.conv_algo = "split3" if getattr(trk.vgg, "split3", False) else trk.vgg.algo
+    if args.conv_algo is None:                                      # what the tracker's pipeline runs (reported below)
+        pipe_split3 = getattr(trk.vgg, "split3", False) and (args.mode != "train" or getattr(trk, "pipeline_trunk_split3", True))
+        args.conv_algo = "split3" if pipe_split3 else trk.vgg.algo
+    trk.vgg.split3 = getattr(trk.vgg, "split3", False) and args.conv_algo == "split3"     # the probes outside the pipeline run the same form
     log("tracker built; generating synthetic inputs")
     from ntmtrack import parallel
     lo, hi = parallel.shard_range(world * B, rank, world)          # this rank's sequences of the global batch
@@ -411,12 +413,12 @@ def main():
             e0, e1 = ev(), ev()
             with torch.cuda.stream(s_vgg):
                 e0.record()
-            trk.submit_features(frames)
+            trk.submit_features(frames, beside=args.mode)
             with torch.cuda.stream(s_vgg):
                 e1.record()
             marks_vgg.append((e0, e1))
         else:
-            trk.submit_features(frames)
+            trk.submit_features(frames, beside=args.mode)
 
     def consume(timed):
         """NTM forward + BPTT + all-reduce + optimiser of the oldest submitted batch."""

@@ -173,9 +173,10 @@ class _TwoStreamPipeline(object):
             self._s_vgg = self._s_ntm if self.serial_trunk else torch.cuda.Stream(device=self.device)
         return self._s_vgg, self._s_ntm
 
-    def submit_features(self, frames):
+    def submit_features(self, frames, beside="train"):
         """Enqueue the VGG trunk for `frames` on the feature stream (returns immediately).
-        At most two submissions may be outstanding."""
+        At most two submissions may be outstanding.  `beside`: what the core stream runs meanwhile, "train" (a training pass of the
+        previous batch: the default) or "infer" (its forward only) -- the DNC tracker picks the trunk's form by it."""
         s_vgg, _ = self._streams()
         if len(self._pending) >= 2:
             raise _lib.NtkError("submit_features: two feature batches already outstanding")
@@ -194,7 +195,12 @@ class _TwoStreamPipeline(object):
         if slot["free"] is not None:
             s_vgg.wait_event(slot["free"])                               # core pass that last read this buffer is done
         with torch.cuda.stream(s_vgg):
-            self.vgg(frames, out=slot["buf"])
+            keep = getattr(self.vgg, "split3", False)
+            self.vgg.split3 = keep and (beside != "train" or getattr(self, "pipeline_trunk_split3", True))    # (DNCOffsetTracker.__init__)
+            try:
+                self.vgg(frames, out=slot["buf"])
+            finally:
+                self.vgg.split3 = keep
             done = torch.cuda.Event()
             done.record(s_vgg)
         self._pending.append((slot, done))
@@ -329,11 +335,13 @@ class DNCOffsetTracker(_TwoStreamPipeline, _Checkpointing):
         self.B, self.T = int(batch_size), int(sequence_length)
         self.S = self.T * (NUM_FEATURES + 1)
         self.device = torch.device(device)
-        if conv_algo is None:
-            # The DNC steps are bound by their cluster kernels, which share the chip (and its clock) with the trunk: beside the split-form
-            # trunk (the fp16 matrix pipe at 1.6 - 1.75 GHz) they run 2 % slower than beside the Winograd trunk, and the trunk's own time
-            # is hidden either way (configs[2]: 6 020 against 6 145 frames/s, same box) -> the Winograd form unless asked otherwise
-            conv_algo = os.environ.get("NTK_TRUNK_ALGO", "winograd")
+        # The pipelined DNC training step is bound by its cluster kernels, which share the chip (and its clock) with the trunk pass of
+        # the next batch: beside the split-form trunk (the fp16 matrix pipe at 1.6 - 1.75 GHz) they run 2 % slower than beside the Winograd
+        # trunk, and the trunk's own time is hidden either way (configs[2]: 6 020 against 6 145 frames/s, same box).  A trunk pass that
+        # runs ALONE (infer, train_step) or beside the forward only is 13 % shorter in the split form (pipelined DNC inference: 11 170
+        # against 9 760 frames/s).  So, unless a form was asked for: the split form, except for the trunk passes submit_features() puts
+        # beside a TRAINING pass.
+        self.pipeline_trunk_split3 = not (conv_algo is None and "NTK_TRUNK_ALGO" not in os.environ)
         self.vgg = VGG16Conv43(vgg_weights, device=self.device, chunk_frames=vgg_chunk_frames, dtype=conv_dtype, algo=conv_algo) if vgg_weights else None
         self.features_roi = bool(features_roi) and self.vgg is not None and conv_dtype == "f32" and self.vgg.algo == "winograd"
         if self.features_roi:          # conv4_3 only where extract_features reads it (GRID_START .. GRID_START + (GRID_N - 1) * GRID_STEP), whole 4x4 tiles
