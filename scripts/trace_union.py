@@ -8,7 +8,8 @@ import csv, sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 conv = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows
-               if "conv3x3_wino43" in r["Kernel_Name"] or "conv_c3_rows_kernel" in r["Kernel_Name"]), key=lambda x: x[0])
+               if "conv3x3_wino43" in r["Kernel_Name"] or "conv_c3_rows_kernel" in r["Kernel_Name"]
+               or "conv3x3_relu_bf16p_kernel" in r["Kernel_Name"]), key=lambda x: x[0])          # (the split / bf16 patch-form layers)
 # a pass = one conv1_1 launch per stream part + nine layers each: consecutive passes never overlap (the trunk stream joins its
 # side streams at the end of a pass), so the start-sorted kernels split into equal groups
 nparts = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # stream parts of a trunk pass (VGG16Conv43.split_streams)
