@@ -535,6 +535,11 @@ def main():
                          "traffic": (TRUNK_TRAFFIC_BYTES_640_FRAMES[args.conv_algo] * (B * T) / 640.0)
                          if (args.conv_dtype == "f32" and TRUNK_TRAFFIC_BYTES_640_FRAMES.get(args.conv_algo)) else None,
                          "traffic_note": "HBM-side bytes per trunk pass from PMC FETCH_SIZE*2+WRITE_SIZE (%s), scaled by frames/640; algorithmic 4.563e10 B per 640 frames" % TRUNK_TRAFFIC_PROFILE.get(args.conv_algo),
+                         **({"pipe_busy_pmc": [0.61, 0.83], "clock_ghz_pmc": [1.55, 1.85],
+                             "pmc_note": "profiles/r04_split3_pmc.txt (a separate --pmc pass over the nine split-form layers, 640 frames each): share of SIMD cycles "
+                                         "with the fp16 MFMA pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles; conv2_1 0.61, conv1_2 0.68, the 128- to 512-channel "
+                                         "layers 0.77 - 0.83) and the clock the chip holds in these kernels (GRBM_GUI_ACTIVE / 8 / duration; 2.4 GHz nominal): "
+                                         "frac = busy x clock / 2.4 within a few per cent"} if split3 else {}),
                          "algorithmic_flops_per_frame": conv_flops_per_frame(),
                          "executed_flops_per_frame": executed_flops / (B * T),
                          "algorithmic_tflops": round(algorithmic, 2),
