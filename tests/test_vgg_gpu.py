@@ -395,6 +395,52 @@ def test_winograd43_window_equals_whole_frame_inside_and_touches_nothing_outside
         vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=(0, 4, 24, 8))      # outside the frame
 
 
+def test_trackers_pick_the_trunk_form_per_pass(cuda):
+    """The NTM tracker runs the split-form trunk everywhere; the DNC tracker runs it for trunk passes that are alone or beside an
+    inference pass and the F(4x4) Winograd form for the passes submit_features() puts beside a TRAINING pass (its cluster kernels
+    are the bound there and run faster beside the Winograd trunk: tracker.py); an explicit conv_algo is obeyed everywhere."""
+    from ntmtrack import tracker
+    rng = np.random.default_rng(17)
+    ws = O.init_vgg_weights(rng)
+    B, T = 2, 2
+    frames = torch.from_numpy((rng.uniform(0, 255, size=(B * T, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)).to(cuda)
+    gts0 = torch.from_numpy(rng.uniform(0, 1, size=(B, 64)).astype(np.float32)).to(cuda)
+
+    def forms_seen(trk, fn):
+        seen = []
+        orig = trk.vgg.forward_chunk
+        def spy(fr, upto="conv4_3", out=None):
+            seen.append(bool(trk.vgg.split3) and trk.vgg.split3_trunk_supported(fr.shape))
+            return orig(fr, upto=upto, out=out)
+        trk.vgg.forward_chunk = spy
+        try:
+            fn()
+            trk.join() if hasattr(trk, "join") else None
+            torch.cuda.synchronize()
+        finally:
+            trk.vgg.forward_chunk = orig
+        return seen
+
+    def drain(trk):
+        trk._pending.clear()
+
+    ntm = tracker.NTMOffsetTracker(B, T, vgg_weights=ws, device=cuda, seed=3)
+    assert forms_seen(ntm, lambda: ntm.submit_features(frames)) == [True]
+    drain(ntm)
+    dnc = tracker.DNCOffsetTracker(B, T, vgg_weights=ws, device=cuda, seed=3, mem_size=64, mem_dim=16)
+    assert forms_seen(dnc, lambda: dnc.submit_features(frames)) == [False]                     # beside a training pass: Winograd
+    drain(dnc)
+    assert forms_seen(dnc, lambda: dnc.submit_features(frames, beside="infer")) == [True]
+    drain(dnc)
+    assert forms_seen(dnc, lambda: dnc.infer(frames, gts0)) == [True]                          # alone: the split form
+    assert dnc.vgg.split3                                                                      # ... and the choice is per pass, not sticky
+    asked = tracker.DNCOffsetTracker(B, T, vgg_weights=ws, device=cuda, seed=3, mem_size=64, mem_dim=16, conv_algo="split3")
+    assert forms_seen(asked, lambda: asked.submit_features(frames)) == [True]
+    drain(asked)
+    wino = tracker.DNCOffsetTracker(B, T, vgg_weights=ws, device=cuda, seed=3, mem_size=64, mem_dim=16, conv_algo="winograd")
+    assert forms_seen(wino, lambda: wino.infer(frames, gts0)) == [False]
+
+
 def test_tracker_features_roi_is_invisible_to_the_recurrent_core(cuda):
     """features_roi=True computes conv4_3 only where extract_features reads it (a window of the F(4x4) Winograd kernel: the trunk then
     runs the Winograd form): the serialised NTM input, the loss and the gradients are bit-identical to the whole-map Winograd tracker's."""
