@@ -1,4 +1,10 @@
-// bf16 conv3x3 SAME + bias + ReLU (+ fused 2x2/2 max-pool) for BASELINE config 5's trunk, PATCH form (round 4).
+// conv3x3 SAME + bias + ReLU (+ fused 2x2/2 max-pool) on the 16-bit matrix pipe, PATCH form (round 4).  Two operators share this kernel:
+//   * the bf16 trunk of BASELINE config 5 (bf16 operands, fp32 accumulate): ntk_vgg_conv3x3_relu_bf16p;
+//   * the SPLIT form of the fp32 trunk (template flag X3, further down): every fp32 value as two fp16 numbers, every product as
+//     three fp16 MFMA products with fp32 accumulators -- the default trunk of BASELINE configs 1 and 3's NTM tracker:
+//     ntk_vgg_conv3x3_relu_split3.
+// What follows describes the kernel on the bf16 operator; the split form differs in what a "step" is, in the epilogue's split and
+// in the 28-wide maps (see the comment in front of the kernel).
 //
 // conv_bf16.hip's kernel re-stages a 128-pixel x 64-channel A tile from L2 for every one of the nine taps and a 128-column
 // B tile beside it: 512 B of global -> LDS traffic per v_mfma_f32_32x32x16_bf16, at four workgroups per CU exactly the

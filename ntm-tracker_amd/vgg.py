@@ -300,8 +300,11 @@ class VGG16Conv43(object):
     """Frozen VGG-16 trunk up to conv4_3/Relu.
 
     weights: {layer_name: (w_hwio [3,3,Cin,Cout], b [Cout])} as numpy arrays or tensors.
-    dtype "f32" (BASELINE configs 2-4: exact fp32 MFMA) or "bf16" (config 5: bf16 operands, fp32 accumulate;
-    conv1_1 reads the fp32 frames, conv4_3 writes fp32 for the memory cell).
+    dtype "f32" (BASELINE configs 2-4: fp32 values and accumulators; `algo` picks the form -- None / "split3": conv1_2 .. conv4_3
+    as three fp16 MFMA products per fp32 product of hi / lo parts (DESIGN.md 4.0''; error at or below the Winograd form's),
+    "winograd" / "winograd2": fused Winograd on the fp32 MFMA pipe, "direct": the implicit-GEMM kernel; NTK_TRUNK_ALGO overrides
+    the default) or "bf16" (config 5: bf16 operands, fp32 accumulate; conv1_1 reads the fp32 frames, conv4_3 writes fp32 for the
+    memory cell).
     """
 
     def __init__(self, weights, device="cuda", chunk_frames=1024, dtype="f32", algo=None):
