@@ -76,6 +76,32 @@ __device__ __forceinline__ float wave_max(float v) {
                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
 }
 
+// ntk_stream_matvec (below) with the prefetch cut at the slice's end: rows at or past r1 are not loaded (the loads sit under lane
+// predicates; same products in the same order).  The plain form fetches 2 PF rows past a slice -- 15 rows for nothing per 25-row
+// slice of the NTM BPTT's read columns.  Measured (B32 x S1300, alone): BPTT 20.1 -> 19.4 ms with this form in its three
+// products; the forward's unpack product is 0.9 ms SLOWER with it (its extra rows are L1 hits, the predicates are not free), so
+// only the BPTT kernel uses it.
+template <int PF>
+__device__ __forceinline__ f32x4 ntk_stream_matvec_exact(const f32x4* __restrict__ w4, int stride4, const float* __restrict__ x, int r0, int r1,
+                                                         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}) {        // acc: the sum so far (rows before r0)
+    f32x4 wa[PF], wb[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) { wa[q] = f32x4{0.f, 0.f, 0.f, 0.f}; if (r0 + q < r1) wa[q] = w4[(size_t)(r0 + q) * stride4]; }
+#pragma unroll
+    for (int q = 0; q < PF; ++q) { wb[q] = f32x4{0.f, 0.f, 0.f, 0.f}; if (r0 + PF + q < r1) wb[q] = w4[(size_t)(r0 + PF + q) * stride4]; }
+    for (int r = r0; r < r1; r += 2 * PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) acc += ((r + q < r1) ? x[r + q] : 0.f) * wa[q];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) if (r + 2 * PF + q < r1) wa[q] = w4[(size_t)(r + 2 * PF + q) * stride4];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) acc += ((r + PF + q < r1) ? x[r + PF + q] : 0.f) * wb[q];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) if (r + 3 * PF + q < r1) wb[q] = w4[(size_t)(r + 3 * PF + q) * stride4];
+    }
+    return acc;
+}
+
 // Streaming mat-vec slice: sum_{r = r0}^{r1 - 1} x[r] * w4[r * stride4] with two register batches of PF rows in flight.
 // Written out explicitly because the compiler, left alone, sinks every load to just before its use (one 16-byte
 // load in flight per thread): fine while the weights hit L2, 2.5-2.8x slower when a concurrent kernel evicts them.

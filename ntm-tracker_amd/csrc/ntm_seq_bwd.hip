@@ -305,6 +305,15 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         }
         __syncthreads();
     }
+    // WS: the first NTMB_RES_B11 rows of every compute thread's 25-row slice of B11's read columns stay in registers for the whole
+    // launch (the kernel has 146 of the 168 registers twelve waves allow): 51 of the 256 KB that product draws from L2 per step
+    constexpr int NTMB_RES_B11 = 5;
+    f32x4 wres11[NTMB_RES_B11];
+    if constexpr (WS) {
+        const int cg = tid0 % 20, sl = tid0 / 20;
+#pragma unroll
+        for (int q = 0; q < NTMB_RES_B11; ++q) wres11[q] = reinterpret_cast<const f32x4*>(a.WrT)[(size_t)(sl * 25 + q) * kg4 + cg];
+    }
 #ifdef NTK_CL_PROF
     unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + L.total);      // 128 B behind the state (the launch adds them)
     if (threadIdx.x == 0) { for (int i = 0; i < 15; ++i) s_prof[i] = 0; s_prof[15] = __builtin_amdgcn_s_memtime(); }
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
             if constexpr (FIX) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const int cs = min(c1, c0 + NTMB_RES_WA);
-                const f32x4 str = ntk_stream_matvec<4>(reinterpret_cast<const f32x4*>(a.WaT) + cg, hg4, sDU, cs, c1, PP - 1);
+                const f32x4 str = ntk_stream_matvec_exact<4>(reinterpret_cast<const f32x4*>(a.WaT) + cg, hg4, sDU, cs, c1);
 #pragma unroll
                 for (int q = 0; q < NTMB_RES_WA; ++q) acc += ((c0 + q < c1) ? sDU[c0 + q] : 0.f) * sWaRes4[q * (nslH * hg4) + tid];
                 sPart4[sl * hg4 + cg] = acc + str;
@@ -649,7 +658,10 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_bwd_kernel(NtmBwdArgs a, NtmBwdL
         if constexpr (WS) {
             // the 80 read columns only (20 float4 column groups x 32 row slices of 25): the h columns are the stream waves'
             const int cg = tid % 20, sl = tid / 20;
-            sPart4[sl * 20 + cg] = ntk_stream_matvec<4>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, sl * 25, sl * 25 + 25, 4 * hid - 1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NTMB_RES_B11; ++q) acc += sDG[sl * 25 + q] * wres11[q];       // (same order of the 25 rows as before)
+            sPart4[sl * 20 + cg] = ntk_stream_matvec_exact<4>(reinterpret_cast<const f32x4*>(a.WrT) + cg, kg4, sDG, sl * 25 + NTMB_RES_B11, sl * 25 + 25, acc);
         } else if (tid < nslZ * kg4) {
             const int cg = tid % kg4, sl = tid / kg4;
             const int r0 = sl * nperZ, r1 = min(4 * hid, r0 + nperZ);
