@@ -217,6 +217,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __shared__ __attribute__((aligned(1024))) unsigned char s_mem[LDSB];
     // s_mem: two patch buffers of ABYTES, then two weight-stage buffers of SBYTES
     __shared__ int s_sbf[NSUB], s_sby[NSUB], s_sbx[NSUB];
+    // the column block's biases (and the split form's output scale) are fetched with the tables: read from global memory in the
+    // epilogue they were eight dependent round trips at the very end of a workgroup that is alone on its CU
+    __shared__ __attribute__((aligned(16))) float s_bias[BN + 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,6 +238,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     // ROWS: first pixel of the run, its global row g0 = (frame rf0, row ry0)
     const int rP0 = sp * (32 * PNT), rg0 = ROWS ? rP0 / TW : 0, rf0 = ROWS ? rg0 / H : 0, ry0 = ROWS ? rg0 - rf0 * H : 0;
+    if (tid < BN) s_bias[tid] = a.bias[cb * BN + tid];
+    if (X3 && tid == BN) s_bias[BN] = *reinterpret_cast<const float*>(a.wq + (size_t)9 * a.Cin * a.Cout);
     if (!ROWS && tid < NSUB) {
         const int sq = sp * NSUB + tid;
         if (sq < a.NQ) {
@@ -573,15 +578,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---- epilogue: register r of acc[tm][nt] = channel nt * 32 + 8 (r >> 2) + 4 kh + (r & 3) of this lane's pixel
     const int nbase = cb * BN + wn * 64 + 4 * kh;
-    float oscale = 1.f;                                                         // split form: the inverse of the weights' power-of-two scale
-    if constexpr (X3) oscale = *reinterpret_cast<const float*>(a.wq + (size_t)9 * Cin * Cout);
+    const float oscale = X3 ? s_bias[BN] : 1.f;                                 // split form: the inverse of the weights' power-of-two scale
     if constexpr (POOL) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nbase + nt * 32 + 8 * g;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + n - cb * BN);
 #pragma unroll
                 for (int tm = 0; tm < TM; tm += 2) {
                     f32x4 v;
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (WIDE && nt != ps) continue;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + nbase + nt * 32 + 8 * g);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + nbase - cb * BN + nt * 32 + 8 * g);
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
                         f32x4 v;
