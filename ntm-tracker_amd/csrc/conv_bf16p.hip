@@ -31,7 +31,7 @@
 #include <type_traits>
 
 // Ablation switches (timing only, results wrong; never defined in the product build): bit 0 no DMA after the prologue, bit 1 no
-// workgroup barrier / DMA wait in the K loop, bit 2 fragments not re-read (one set for the whole kernel), bit 3 no MFMAs
+// workgroup barrier / DMA wait in the K loop, bit 2 fragments not re-read (one set for the whole kernel), bit 3 no MFMAs, bit 4 no epilogue
 #ifndef BF16P_ABL
 #define BF16P_ABL 0
 #endif
@@ -88,12 +88,15 @@ __device__ __forceinline__ ph16x8 p_as_f16x8(const f32x4& v) {
 // The split form's two parts of four fp32 values: hi = fp16(v) rounded TOWARD ZERO (v_cvt_pkrtz_f16_f32: a value beyond the fp16
 // range saturates at 65504 instead of becoming infinite, and lo then carries the rest up to 131008), lo = fp16(v - hi) rounded to
 // nearest: v = hi + lo to 2^-22 |v| (eleven + eleven bits) for 6e-5 < |v| < 65504; below, to fp16's absolute 6e-8.
+// PRECONDITION: |v| <= S3_MAX = 131008 (the callers clamp: the epilogues with the same v_med3_f32 that is their ReLU) -- so that
+// lo cannot overflow either.
 __device__ __forceinline__ void s3_split4(const f32x4& v, ph16x4& hi, ph16x4& lo) {
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
     hi = ph16x4{(_Float16)h01[0], (_Float16)h01[1], (_Float16)h23[0], (_Float16)h23[1]};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) lo[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e] - (float)hi[e], -65504.f, 65504.f);      // (saturating as well)
+    for (int e = 0; e < 4; ++e) lo[e] = (_Float16)(v[e] - (float)hi[e]);
 }
+constexpr float S3_MAX = 131008.f;
 
 // 16-byte piece `piece` of LDS pixel / column `idx` lives in slot piece ^ sw(idx): PIECES = 4 (64-byte rows): bits 2..3 of the
 // index; PIECES = 2 (32-byte rows): bit 3 -- sixteen consecutive indices then cover all 64 banks once per ds_read_b128 group
@@ -310,7 +313,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     auto f32_put = [&](const f32x4& v, int dst) {                               // split one item into the patch image at byte dst of s_mem
         ph16x4 h, l;
-        s3_split4(v, h, l);
+        f32x4 c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e], -S3_MAX, S3_MAX);
+        s3_split4(c, h, l);
         *reinterpret_cast<ph16x4*>(s_mem + dst) = h;
         *reinterpret_cast<ph16x4*>(s_mem + (dst ^ 32)) = l;
     };
@@ -576,6 +582,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int tm = 0; tm < TM; ++tm) xa[tap][tm] += flip;
     }
 
+    if constexpr ((BF16P_ABL & 16) != 0) {                                       // ablation: no epilogue (one store keeps the accumulators alive)
+        float sacc = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[tm][nt][r];
+        if (sacc == 12345.f) reinterpret_cast<float*>(a.out)[tid] = sacc;
+        return;
+    }
     // ---- epilogue: register r of acc[tm][nt] = channel nt * 32 + 8 (r >> 2) + 4 kh + (r & 3) of this lane's pixel
     const int nbase = cb * BN + wn * 64 + 4 * kh;
     const float oscale = X3 ? s_bias[BN] : 1.f;                                 // split form: the inverse of the weights' power-of-two scale
@@ -593,7 +610,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int e = 0; e < 4; ++e) {
                         const float m2 = fmaxf(acc[tm][nt][4 * g + e], acc[tm + 1][nt][4 * g + e]);        // rows y, y + 1
                         const float m4 = fmaxf(m2, ntk_dpp<0xB1>(m2));                                    // columns x, x ^ 1
-                        v[e] = fmaxf((X3 ? m4 * oscale : m4) + bv[e], 0.f);
+                        if constexpr (X3 && !OUTF32) v[e] = __builtin_amdgcn_fmed3f(m4 * oscale + bv[e], 0.f, S3_MAX);   // ReLU and the split's range in one
+                        else v[e] = fmaxf((X3 ? m4 * oscale : m4) + bv[e], 0.f);
                     }
                     if (opix[tm] >= 0 && (mcol & 1) == 0) {
                         if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)opix[tm] * Cout + n) = v;
@@ -636,7 +654,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int tm = 0; tm < TM; ++tm) {
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf((X3 ? acc[tm][nt][4 * g + e] * oscale : acc[tm][nt][4 * g + e]) + bv[e], 0.f);
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (X3 && !OUTF32) v[e] = __builtin_amdgcn_fmed3f(acc[tm][nt][4 * g + e] * oscale + bv[e], 0.f, S3_MAX);
+                            else v[e] = fmaxf((X3 ? acc[tm][nt][4 * g + e] * oscale : acc[tm][nt][4 * g + e]) + bv[e], 0.f);
+                        }
                         unsigned char* row = tr + (tm * 32 + mcol) * RB;
                         if constexpr (OUTF32) *reinterpret_cast<f32x4*>(row + (8 * g + 4 * kh) * 4) = v;
                         else if constexpr (X3) {                                // the half's two 16-channel groups: [hi x16 | lo x16] x 2
@@ -659,8 +680,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int j = 0; j < TM * 4; ++j) {
                 const int tmr = j >> 2, mr = 8 * (j & 3) + (lane >> 3), piece = lane & 7;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tr + (tmr * 32 + mr) * RB + piece * 16);
-                int pc_, opx;
-                locate(wm * TM + tmr, mr, pc_, opx);
+                // the output pixel of row (tile tmr, column mr) is what lane mr holds in opix[tmr]: one cross-lane read instead of
+                // redoing the tile -> pixel map (index arithmetic, table reads and a 64-bit multiply per row: that was 40 % of the epilogue's
+                // instructions, and the epilogue is vector-ALU bound)
+                const int opx = __builtin_amdgcn_ds_bpermute(mr << 2, opix[tmr]);
                 if (opx >= 0) {
                     const size_t op = (size_t)opx * Cout + cb * BN + wn * 64;
                     if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + op + ps * 32 + piece * 4) = v;

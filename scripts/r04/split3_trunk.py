@@ -48,5 +48,5 @@ for upto in ("conv3_3", "conv2_2", "conv4_3"):
 for label, net in nets:
     y = net(frames[:3].contiguous())
     err = (y.double() - r).abs().max().item() / s
-    print("%-24s max err / max|y| vs fp64 trunk %.2e   640-frame pass: %.3f ms (1 part)  %.3f ms (2 parts)"
-          % (label, err, timeit(net, 1), timeit(net, 2)), flush=True)
+    print("%-24s max err / max|y| vs fp64 trunk %.2e   640-frame pass: %.3f ms (1 part)  %.3f ms (2 parts)  %.3f ms (3)  %.3f ms (4)"
+          % (label, err, timeit(net, 1), timeit(net, 2), timeit(net, 3), timeit(net, 4)), flush=True)
