@@ -17,6 +17,9 @@
 #pragma once
 #include "common.h"
 
+// shift taps the sequence kernels hold in registers: shift_range <= 4 (the reference's default and every BASELINE config use 1)
+constexpr int NTM_MAX_SHIFT_TAPS = 9;
+
 struct NtmDims {
     int B, S;          // sequences, steps
     int N, Md;         // memory slots, word size          (mem_size, mem_dim)

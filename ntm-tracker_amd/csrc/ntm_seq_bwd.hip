@@ -55,9 +55,9 @@ struct NtmBwdLds {
         Khat, Ks, Kinv, Kss, Cinv, Css, C2, Dkhat, Sw, Red, Dmh, total;
 };
 
-constexpr int NQ = 6;        // max simultaneous per-head reductions in one stage
-constexpr int NQT = 11;      // reduction slots per head; every stage owns its own slots (no read/write reuse inside a step)
-constexpr int QR1 = 0, QR2 = 2, QR3 = 8, QR4 = 10;
+constexpr int NQ = 1 + NTM_MAX_SHIFT_TAPS;   // max simultaneous per-head reductions in one stage (d gamma + one per shift tap)
+constexpr int QR1 = 0, QR2 = 2, QR3 = QR2 + NQ, QR4 = QR3 + 2;
+constexpr int NQT = QR4 + 1; // reduction slots per head; every stage owns its own slots (no read/write reuse inside a step)
 constexpr int MAXM = 8;      // max memory elements prefetched per thread
 constexpr int NTMB_RES_WA = 7;   // benchmark shape: rows of Wa^T per thread (of its 15) kept in the LDS the state leaves free
 

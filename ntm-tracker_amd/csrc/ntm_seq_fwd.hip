@@ -252,16 +252,17 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             if (lane < Md) sKs[h * Md + lane] = sU[d.oK + h * Md + lane] * kinv * sCn[lane];
             for (int m = lane + 64; m < Md; m += 64) sKs[h * Md + m] = sU[d.oK + h * Md + m] * kinv * sCn[m];
             const float beta = sU[d.oB + h], g = sU[d.oG + h], gamma = sU[d.oY + h];
-            float swv[5];                                          // softmax of the shift logits (ntm_cell.py:161)
+            constexpr int MAXSS = FIX ? 3 : NTM_MAX_SHIFT_TAPS;     // (a compile-time 3 taps at the benchmark shape)
+            float swv[MAXSS];                                      // softmax of the shift logits (ntm_cell.py:161)
             {
                 float mx = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) if (j < SS) mx = fmaxf(mx, sU[d.oS + h * SS + j]);
+                for (int j = 0; j < MAXSS; ++j) if (j < SS) mx = fmaxf(mx, sU[d.oS + h * SS + j]);
                 float sum = 0.f;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { swv[j] = (j < SS) ? ntm_exp(sU[d.oS + h * SS + j] - mx) : 0.f; sum += swv[j]; }
+                for (int j = 0; j < MAXSS; ++j) { swv[j] = (j < SS) ? ntm_exp(sU[d.oS + h * SS + j] - mx) : 0.f; sum += swv[j]; }
 #pragma unroll
-                for (int j = 0; j < 5; ++j) swv[j] = swv[j] / sum;
+                for (int j = 0; j < MAXSS; ++j) swv[j] = swv[j] / sum;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(MAXT) void ntm_seq_fwd_kernel(NtmFwdArgs a, NtmLds 
             for (int n = lane; n < N; n += 64) {
                 float wv = 0.f;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
+                for (int j = 0; j < MAXSS; ++j) {
                     if (j < SS) {
                         int src = n + start + j;
                         src = (src % N + N) % N;
@@ -397,9 +398,10 @@ int ntm_validate_dims(const NtmDims& d, const char* who) {
                     d.R * d.Md <= 1024,
                 NTK_ERR_UNSUPPORTED, "%s: hidden=%d heads=%d mem_dim=%d exceed one workgroup", who, d.hid, d.H, d.Md);
     NTK_REQUIRE(d.SS >= 1 && d.SS < d.N && d.O >= 1, NTK_ERR_BAD_SHAPE, "%s: shift space %d / output_dim %d", who, d.SS, d.O);
-    // limits of the kernels' fixed decomposition: shift taps live in a 5-element register array, addressing runs one
-    // WAVE per head, and the column norms of M need one wave beyond those of the hidden units
-    NTK_REQUIRE(d.SS <= 5, NTK_ERR_UNSUPPORTED, "%s: shift_range=%d (shift space %d > 5 taps)", who, (d.SS - 1) / 2, d.SS);
+    // limits of the kernels' fixed decomposition: shift taps live in a register array of NTM_MAX_SHIFT_TAPS (9: shift_range <= 4),
+    // addressing runs one WAVE per head, and the column norms of M need one wave beyond those of the hidden units
+    NTK_REQUIRE(d.SS <= NTM_MAX_SHIFT_TAPS, NTK_ERR_UNSUPPORTED, "%s: shift_range=%d (shift space %d > %d taps)", who, (d.SS - 1) / 2, d.SS,
+                NTM_MAX_SHIFT_TAPS);
     NTK_REQUIRE((d.H + 1) * 64 <= 1024, NTK_ERR_UNSUPPORTED, "%s: %d heads (one wave per head: at most 15)", who, d.H);
     NTK_REQUIRE(((d.hid + 63) / 64 + 1) * 64 <= 1024, NTK_ERR_UNSUPPORTED, "%s: hidden=%d (at most 960)", who, d.hid);
     return NTK_OK;

@@ -39,6 +39,10 @@ CASES = [
                                     controller_num_layers=1, write_head_size=2, read_head_size=3, write_first=True), 10, 7, 2),
     ("batch1_odd_dims", dict(mem_size=192, mem_dim=13, shift_range=1, controller_hidden_size=77, controller_num_layers=1,
                              write_head_size=1, read_head_size=2), 9, 5, 1),
+    ("shift_range_3", dict(mem_size=64, mem_dim=8, shift_range=3, controller_hidden_size=48, controller_num_layers=1,
+                           write_head_size=1, read_head_size=2), 10, 6, 2),
+    ("shift_range_4", dict(mem_size=128, mem_dim=6, shift_range=4, controller_hidden_size=40, controller_num_layers=1,
+                           write_head_size=2, read_head_size=1, write_first=True), 7, 5, 2),      # nine taps: the kernels' widest
 ]
 
 
@@ -131,9 +135,9 @@ def test_unsupported_configs_fail_loudly(cuda):
     with pytest.raises(NtkError):                                   # mem_size must be a multiple of 64
         st = cell.zero_state(1)
         cell(torch.zeros((1, 8), device=cuda), st)
-    # limits of the fused kernel's decomposition are refused, never computed wrongly: shift_range 3
-    # (7 taps > the 5-tap register array), 16 heads (one wave per head), hidden 1000 (> 960)
-    for kw in (dict(shift_range=3, write_head_size=1, read_head_size=1, controller_hidden_size=64),
+    # limits of the fused kernel's decomposition are refused, never computed wrongly: shift_range 5
+    # (11 taps > the 9-tap register array; up to 4 is served since round 4), 16 heads (one wave per head), hidden 1000 (> 960)
+    for kw in (dict(shift_range=5, write_head_size=1, read_head_size=1, controller_hidden_size=64),
                dict(shift_range=1, write_head_size=8, read_head_size=8, controller_hidden_size=64, mem_dim=4),
                dict(shift_range=1, write_head_size=1, read_head_size=1, controller_hidden_size=1000)):
         c = NTMCell(2, mem_size=64, mem_dim=kw.pop("mem_dim", 8), controller_num_layers=1, input_dim=8, device=cuda, **kw)

@@ -53,6 +53,10 @@ GRAD_CASES = [
                      write_head_size=1, read_head_size=1), 514, 2, 2, 0.1),
     ("write_first_2w", dict(mem_size=64, mem_dim=8, shift_range=1, controller_hidden_size=64, controller_num_layers=1,
                             write_head_size=2, read_head_size=2, write_first=True), 514, 2, 3, 0.2),
+    ("shift_range_3", dict(mem_size=64, mem_dim=8, shift_range=3, controller_hidden_size=48, controller_num_layers=1,
+                           write_head_size=1, read_head_size=2), 514, 2, 2, 0.2),
+    ("shift_range_4", dict(mem_size=128, mem_dim=8, shift_range=4, controller_hidden_size=48, controller_num_layers=1,
+                           write_head_size=2, read_head_size=1, write_first=True), 514, 2, 2, 0.2),
 ]
 
 
