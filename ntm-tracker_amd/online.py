@@ -75,7 +75,10 @@ class NTMTracker(object):
         """-> serialised block [1, 65, ldx] on the device: delimiter row first, then the 64 feature rows (:370-405)."""
         crop = crop_and_resize(img, self.cropbox)
         self.cropped_input_image = crop
-        fmap = self.vgg(crop.unsqueeze(0))
+        try:
+            fmap = self.vgg(crop.unsqueeze(0), latency=True)             # one frame per call: the trunk form with the shorter critical path
+        except TypeError:                                                # (a caller's own trunk object without the flag)
+            fmap = self.vgg(crop.unsqueeze(0))
         gts0 = None
         if is_first_frame:
             gt = generate_gt(apply_transformation(self.normalized_bbox, self.transformation), self.cropbox_grid, self.bbox_grid)

@@ -337,6 +337,14 @@ class VGG16Conv43(object):
         # fp32 kernel (conv1_2's staging splits its map), the last split layer writes fp32 NHWC for the Winograd layers.
         self.split3 = (algo == "split3" and dtype == "f32")
         self.split3_upto = os.environ.get("NTK_SPLIT3_UPTO", "conv4_3")
+        # __call__(..., latency=True) runs a call of fewer frames than this in the Winograd form: with a handful of frames a layer is
+        # a few workgroups per CU at most and the pass is bound by one workgroup's critical path, which is shorter in the F(4x4)
+        # kernel (224 x 224, one MI355X: 1 frame 0.78 against 0.96 ms, 8 frames 1.00 against 1.09, 12 frames 1.39 against 1.27,
+        # 16 frames 1.57 against 1.44 -- scripts/r04/small_batch_trunk.py).  What the online tracker asks for (one frame per call).
+        # Without the flag every call runs the same form, so a frame's features do not depend on the size of the batch it is in
+        # (bit for bit: tests/test_fullsize_gpu.py).
+        self.split3_latency_frames = 12
+        self._call_split3 = True
         self._packed_split3 = {}
         if self.split3:
             algo = "winograd"                                # everything else (weights packed, layouts, fallbacks) as the Winograd trunk
@@ -457,7 +465,7 @@ class VGG16Conv43(object):
                 raise _lib.NtkError("bf16 trunk runs to conv4_3 only")
             return self._forward_chunk_bf16(frames.contiguous(), out=out)
         x = frames
-        if self.split3 and upto == "conv4_3" and self.split3_trunk_supported(frames.shape):
+        if self.split3 and self._call_split3 and upto == "conv4_3" and self.split3_trunk_supported(frames.shape):
             if out is None:
                 out = torch.empty((frames.shape[0], frames.shape[1] // 8, frames.shape[2] // 8, 512), device=frames.device)
             return self._forward_chunk_split3(frames.contiguous(), out)
@@ -496,8 +504,9 @@ class VGG16Conv43(object):
                 break
         return x
 
-    def __call__(self, frames, out=None):
-        """frames [F,224,224,3] mean-subtracted fp32 NHWC -> [F,28,28,512]."""
+    def __call__(self, frames, out=None, latency=False):
+        """frames [F,224,224,3] mean-subtracted fp32 NHWC -> [F,28,28,512].  latency=True: a call of a few frames may run the form with
+        the shorter critical path (split3_latency_frames) -- same operator, results equal to fp32 rounding, not bit for bit."""
         if frames.dim() != 4 or frames.shape[3] != 3:
             raise _lib.NtkError("frames must be [F,H,W,3] NHWC")
         F, H, W, _ = frames.shape
@@ -506,6 +515,14 @@ class VGG16Conv43(object):
             # gets back must be zero there, not uninitialised memory
             alloc = torch.zeros if getattr(self, "features_window", None) is not None else torch.empty
             out = alloc((F, H // 8, W // 8, 512), device=frames.device, dtype=torch.float32)
+        self._call_split3 = not (latency and F < self.split3_latency_frames)
+        try:
+            return self._run_chunks(frames, out)
+        finally:
+            self._call_split3 = True
+
+    def _run_chunks(self, frames, out):
+        F = frames.shape[0]
         for f0 in range(0, F, self.chunk_frames):
             f1 = min(F, f0 + self.chunk_frames)
             n = self.split_streams if (f1 - f0) >= 32 * self.split_streams else 1

@@ -395,6 +395,23 @@ def test_winograd43_window_equals_whole_frame_inside_and_touches_nothing_outside
         vgg.conv3x3_relu_wino43(x, up, b, cin, cout, out=out, window=(0, 4, 24, 8))      # outside the frame
 
 
+def test_latency_calls_of_a_few_frames_run_the_winograd_form(cuda):
+    """`net(frames, latency=True)` runs a call of fewer than split3_latency_frames (12) frames in the F(4x4) Winograd form (shorter
+    critical path: the online tracker's one frame per call) and larger calls, every chunk of them, in the split form; without the
+    flag every call runs the split form (a frame's features then do not depend on the batch it is in)."""
+    from ntmtrack import vgg
+    rng = np.random.default_rng(31)
+    ws = O.init_vgg_weights(rng)
+    net = vgg.VGG16Conv43(ws, device=cuda, chunk_frames=16)
+    wino = vgg.VGG16Conv43(ws, device=cuda, algo="winograd", chunk_frames=16)
+    x = torch.from_numpy((rng.uniform(0, 255, size=(20, 224, 224, 3)).astype(np.float32) - O.VGG_MEAN)).to(cuda)
+    small = x[:4].contiguous()
+    assert torch.equal(net(small, latency=True), wino(small))                          # small latency call: the Winograd form's bits
+    assert not torch.equal(net(small), wino(small)) and torch.equal(net(small), net(x)[:4])      # default: the split form, batch-invariant
+    assert torch.equal(net(x, latency=True), net(x))                                   # 16 + 4 frames: both chunks in the split form
+    assert _rel(net(small).cpu().numpy(), wino(small).cpu().numpy()) < 1e-5            # the two forms agree to fp32 rounding
+
+
 def test_trackers_pick_the_trunk_form_per_pass(cuda):
     """The NTM tracker runs the split-form trunk everywhere; the DNC tracker runs it for trunk passes that are alone or beside an
     inference pass and the F(4x4) Winograd form for the passes submit_features() puts beside a TRAINING pass (its cluster kernels
@@ -410,7 +427,7 @@ def test_trackers_pick_the_trunk_form_per_pass(cuda):
         seen = []
         orig = trk.vgg.forward_chunk
         def spy(fr, upto="conv4_3", out=None):
-            seen.append(bool(trk.vgg.split3) and trk.vgg.split3_trunk_supported(fr.shape))
+            seen.append(bool(trk.vgg.split3) and trk.vgg._call_split3 and trk.vgg.split3_trunk_supported(fr.shape))
             return orig(fr, upto=upto, out=out)
         trk.vgg.forward_chunk = spy
         try:
