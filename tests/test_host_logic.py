@@ -143,5 +143,7 @@ def test_bench_self_launch_starts_n_ranks_as_a_child_and_returns_its_exit_code()
                           "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert "launching 2 ranks as a child process" in res.stderr
-    assert res.stderr.count("no GPU visible") == 2, res.stderr[-2000:]
+    # both ranks refuse; the elastic launcher may tear the second one down before it has printed its own refusal
+    assert 1 <= res.stderr.count("no GPU visible") <= 2, res.stderr[-2000:]
+    assert "local_rank" in res.stderr or "RANK" in res.stderr, res.stderr[-2000:]
     assert not [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
