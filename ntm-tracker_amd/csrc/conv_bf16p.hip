@@ -31,7 +31,7 @@
 #include <type_traits>
 
 // Ablation switches (timing only, results wrong; never defined in the product build): bit 0 no DMA after the prologue, bit 1 no
-// workgroup barrier / DMA wait in the K loop, bit 2 fragments not re-read (one set for the whole kernel), bit 3 no MFMAs, bit 4 no epilogue
+// workgroup barrier / DMA wait in the K loop, bit 2 fragments not re-read (one set for the whole kernel), bit 3 no MFMAs, bit 4 no epilogue, bit 5 the un-pooled epilogue without its global stores
 #ifndef BF16P_ABL
 #define BF16P_ABL 0
 #endif
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 // redoing the tile -> pixel map (index arithmetic, table reads and a 64-bit multiply per row: that was 40 % of the epilogue's
                 // instructions, and the epilogue is vector-ALU bound)
                 const int opx = __builtin_amdgcn_ds_bpermute(mr << 2, opix[tmr]);
-                if (opx >= 0) {
+                if ((BF16P_ABL & 32) ? (opx >= 0 && v[0] == 12345.f) : (opx >= 0)) {       // (ablation bit 5: everything but the global stores)
                     const size_t op = (size_t)opx * Cout + cb * BN + wn * 64;
                     if constexpr (OUTF32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + op + ps * 32 + piece * 4) = v;
                     else if constexpr (X3) *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.out) + 2 * (op + ps * 32) + piece * 8) = v;
